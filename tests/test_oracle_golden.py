@@ -1,0 +1,132 @@
+"""The oracle (oracle/uformer_wm.py) pinned against goldens produced by the reference itself."""
+import numpy as np
+import torch
+
+from oracle import uformer_wm as O
+from synth import load_synth, synth_array, synth_bits, synth_tile, chirp_wave
+
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), rtol=rtol, atol=atol)
+
+
+def test_g2_stft_roundtrip(golden):
+    g = golden("g2_stft")
+    y = synth_tile(2, "g2_y", 1.0)
+    wave = O.istft255(y)
+    assert wave.shape == (2, 8002)
+    close(wave, g["wave"])
+    close(O.stft255(T(g["wave"])), g["spec"], atol=1e-5)
+
+
+def test_g1_lewin_blocks(golden):
+    for tag, dim, hw, heads, shift, mod in (("a", 32, 16, 1, 0, False), ("b", 64, 16, 2, 4, True)):
+        g = golden("g1_block_" + tag)
+        blk = load_synth(O.LeWinBlock(dim, hw, heads, 8, shift, 0.0, mod)).eval()
+        x = synth_array("g1_x" + tag, (2, hw * hw, dim)).requires_grad_()
+        out = blk(x)
+        out.backward(synth_array("g1_dy" + tag, (2, hw * hw, dim)))
+        close(out, g["out"], atol=1e-5)
+        close(x.grad, g["dx"], rtol=1e-4, atol=1e-5)
+        for k, p in blk.named_parameters():
+            close(p.grad, g["g_" + k.replace(".", "__")], rtol=1e-4, atol=1e-4)
+
+
+def test_g3_model_eval(golden):
+    g = golden("g3_model_eval")
+    net = load_synth(O.UformerAudio()).eval()
+    x, msg = synth_tile(2, "g3_x"), synth_bits("g3_msg", (2, 1, 32, 32))
+    with torch.no_grad():
+        out = net(x, msg)
+        tot, terms = O.train_losses(out, x, msg)
+        for o, k in zip(out, ("stft_new", "noise", "wm_pred", "wm")):
+            close(o, g[k], atol=1e-6)
+        close(tot, g["loss"])
+        close(torch.stack(terms), g["terms"])
+        assert np.array_equal(O.payload_bits(out[3]).numpy().astype(np.uint8), g["bits"])
+        close(net.wm_decode(x), g["wm_decode_x"], atol=1e-6)
+        y, wm = net.feature_extract(x, msg)
+        close(y[:, :, :8, :8], g["fe_y"], atol=1e-6)
+        close(wm, g["fe_wm"], atol=1e-6)
+
+
+def _keeps_from_masks(net, masks):
+    """Re-nest the flat mask list the golden stores (call order; rate-0 blocks draw nothing)."""
+    it = iter(masks)
+
+    def stage(st):
+        out = []
+        for blk in st.blocks:
+            if blk.drop_path_rate > 0:
+                out.append((next(it), next(it)))
+            else:
+                out.append(None)
+        return out
+
+    def trunk(t):
+        return [stage(getattr(t, f"encoderlayer_{i}")) for i in range(4)] + [stage(t.conv)]
+
+    keeps = {"enc": trunk(net.encoder)}
+    keeps["dec"] = [stage(getattr(net.decoder, f"decoderlayer_{i}")) for i in range(4)]
+    keeps["ext"] = trunk(net.decoder_wm)
+    assert next(it, None) is None
+    return keeps
+
+
+def test_g4_model_train_step(golden):
+    g = golden("g4_model_train")
+    net = load_synth(O.UformerAudio()).train()
+    x, msg = synth_tile(2, "g4_x"), synth_bits("g4_msg", (2, 1, 32, 32))
+    keeps = _keeps_from_masks(net, [T(m) for m in g["masks"]])
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    out = net(x, msg, keeps=keeps)
+    tot, terms = O.train_losses(out, x, msg)
+    close(tot, g["loss"], rtol=1e-5)
+    close(torch.stack(terms), g["terms"], rtol=1e-5)
+    close(out[0][:, :, :16, :16], g["stft_new"], atol=1e-5)
+    tot.backward()
+    names = [str(n) for n in g["names"]]
+    assert names == [n for n, p in net.named_parameters() if p.grad is not None]
+    gn = np.array([net.get_parameter(n).grad.norm().item() for n in names])
+    np.testing.assert_allclose(gn, g["gnorm"], rtol=2e-4, atol=1e-6)
+    picks = [k[2:].replace("__", ".") for k in g.files if k.startswith("g_")]
+    for k in picks:
+        close(net.get_parameter(k).grad, g["g_" + k.replace(".", "__")], rtol=1e-3, atol=1e-5)
+    opt.step()
+    for k in picks:
+        close(net.get_parameter(k), g["p_" + k.replace(".", "__")], rtol=1e-5, atol=1e-6)
+
+
+def test_g5_modelA(golden):
+    g = golden("g5_modelA")
+    ma = load_synth(O.ModelA()).eval()
+    x, msg = synth_tile(2, "g5_x"), synth_bits("g5_msg", (2, 1, 32, 32))
+    with torch.no_grad():
+        enc, ext = ma(x, msg)
+    close(enc, g["enc"], atol=1e-6)
+    close(ext, g["ext"], atol=1e-6)
+    ma.train()
+    ma.embedder_decoder[3].p = 0.0
+    enc_t, ext_t = ma(x, msg)
+    loss = torch.nn.functional.mse_loss(x, enc_t) + torch.nn.functional.mse_loss(ext_t, msg)
+    loss.backward()
+    close(loss, g["loss"])
+    close(ma.embedder_encoder[0].weight.grad, g["g_first"], rtol=1e-4, atol=1e-6)
+    close(ma.detector[8].weight.grad, g["g_last"], rtol=1e-4, atol=1e-6)
+
+
+def test_g6_hidden_decoder_and_ber(golden):
+    g = golden("g6_hidden")
+    hd = load_synth(O.HiddenDecoder(64, 7, 30)).eval()
+    x = synth_array("g6_x", (4, 1, 128, 128))
+    with torch.no_grad():
+        dec = hd(x)
+        mid = hd.layers[:9](x)
+    assert dec.shape == (4, 1, 32, 32)
+    close(dec, g["dec"], atol=1e-6)
+    close(mid[:, :, :8, :8], g["mid"], atol=1e-5)
+    bits = synth_bits("g6_bits", (4, 1, 32, 32))
+    assert abs(O.ber(dec, bits).item() - float(g["ber"])) < 1e-7
