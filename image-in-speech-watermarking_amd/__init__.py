@@ -1,0 +1,7 @@
+"""MI355X-native image-in-speech watermark train step (encode -> attack -> decode -> loss).
+
+Hand-written gfx950 HIP kernels (csrc/, C ABI in include/wm_kernels.h) behind the reference's own Python
+surface.  Import with ``importlib.import_module("image-in-speech-watermarking_amd")``.
+"""
+from ._lib import lib, WmKernelError, EXPORTS, LIB_PATH  # noqa: F401  (raises ImportError if the .so is missing)
+from . import ops, attacks  # noqa: F401

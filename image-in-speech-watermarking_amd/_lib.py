@@ -1,0 +1,107 @@
+"""ctypes binding of libwm_hip.so (C ABI declared in include/wm_kernels.h).
+
+The library is the product: there is NO fallback.  If it is missing or a kernel reports an error the
+call raises, so a GPU run can never silently route through PyTorch eager or the CPU oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwm_hip.so")
+
+c_f = C.c_void_p          # device float*
+c_i32, c_i64, c_u64, c_fl = C.c_int32, C.c_int64, C.c_uint64, C.c_float
+
+
+class WmGemm(C.Structure):
+    _fields_ = [("A", c_f), ("B", c_f), ("C", c_f),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32),
+                ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64),
+                ("a_kc", c_i32), ("b_kc", c_i32), ("a_op", c_i32), ("b_op", c_i32),
+                ("bias", c_f), ("res", c_f), ("ldr", c_i64),
+                ("rowscale", c_f), ("rows_per_scale", c_i32),
+                ("kscale", c_f), ("k_per_scale", c_i32),
+                ("gaux", c_f), ("ldg", c_i64),
+                ("b_ones", c_i32), ("C2", c_f),
+                ("atomic_out", c_i32), ("ksplit", c_i32), ("mode", c_i32)]
+
+
+class WmConv(C.Structure):
+    _fields_ = [(n, c_i32) for n in ("B", "Cin", "H", "W", "Cout", "KH", "KW", "SH", "SW", "PH", "PW", "OH", "OW",
+                                      "in_nhwc", "out_nhwc", "act", "transposed")]
+
+
+class WmAttack(C.Structure):
+    _fields_ = [("flags", c_i32), ("snr_db", c_fl), ("amp", c_fl), ("lp_h", c_f), ("lp_n", c_i32),
+                ("rs_h", c_f), ("rs_n", c_i32), ("seed", c_u64), ("step", c_f)]
+
+
+_SIGS = {
+    "wm_abi_version": [],
+    "wm_gemm": [C.POINTER(WmGemm), c_f],
+    "wm_layernorm_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f],
+    "wm_layernorm_bwd": [c_f] * 10 + [c_i64, c_i32, c_i32, c_i32, c_f],
+    "wm_winattn_fwd": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_winattn_bwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_dwconv_fwd": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_f],
+    "wm_dwconv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_f],
+    "wm_im2col_4x4s2": [c_f, c_f, c_i32, c_i32, c_i32, c_f],
+    "wm_col2im_4x4s2": [c_f, c_f, c_i32, c_i32, c_i32, c_f],
+    "wm_pixel_shuffle2": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i64, c_i32, c_f],
+    "wm_pixel_unshuffle2": [c_f, c_f, c_i32, c_i32, c_i32, c_i64, c_i32, c_f],
+    "wm_copy_cols": [c_f, c_i64, c_i32, c_f, c_i64, c_i32, c_i64, c_i32, c_i32, c_f],
+    "wm_strided3": [c_f, c_f, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_f],
+    "wm_msg_expand_fwd": [c_f, c_f, c_i32, c_f],
+    "wm_msg_expand_bwd": [c_f, c_f, c_i32, c_f],
+    "wm_conv_fwd": [C.POINTER(WmConv), c_f, c_f, c_f, c_f, c_f],
+    "wm_conv_bwd": [C.POINTER(WmConv), c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f],
+    "wm_maxpool_fwd": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_maxpool_bwd": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_istft255_fwd": [c_f, c_f, c_i32, c_f],
+    "wm_stft255_fwd": [c_f, c_f, c_i32, c_f],
+    "wm_istft255_bwd": [c_f, c_f, c_i32, c_f],
+    "wm_stft255_bwd": [c_f, c_f, c_i32, c_f],
+    "wm_attack_fwd": [C.POINTER(WmAttack), c_f, c_f, c_f, c_i32, c_i32, c_f],
+    "wm_attack_bwd": [C.POINTER(WmAttack), c_f, c_f, c_f, c_f, c_i32, c_i32, c_f],
+    "wm_loss_fwd_bwd": [c_f] * 11 + [c_i32, c_f, c_f],
+    "wm_adamw": [c_f, c_f, c_f, c_f, c_i64, c_f, c_fl, c_fl, c_fl, c_fl, c_f, c_f, c_f],
+    "wm_step_inc": [c_f, c_f],
+    "wm_droppath_scales": [c_f, c_f, c_i32, c_i32, c_u64, c_f, c_f],
+    "wm_axpbyz": [c_f, c_fl, c_f, c_fl, c_f, c_i64, c_f],
+}
+EXPORTS = tuple(_SIGS)
+
+
+class WmKernelError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP kernels first "
+            "(python -c 'import __graft_entry__ as g; g.build()'  or  make -C image-in-speech-watermarking_amd/csrc). "
+            "There is no PyTorch/CPU fallback for the watermark hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI drift between header and library
+        fn.argtypes = args
+        fn.restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise WmKernelError(f"{what} failed with code {rc}" + (" (unsupported shape/alignment)" if rc == 22 else ""))
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int64 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise WmKernelError("libwm_hip kernels take device tensors only (got a CPU tensor)")
+    return t.data_ptr()

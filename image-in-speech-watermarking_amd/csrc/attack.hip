@@ -1,0 +1,317 @@
+// Fused waveform attacks between the in-graph iSTFT and STFT (hook point reference model.py:2461-2462).
+// The four distortions BASELINE.json names (reference uformerWM/audio_attack.py):
+//   resampling 16k -> 8k -> 16k (:71-83)   polyphase Kaiser-windowed-sinc, 41 taps (scipy resample_poly
+//                                           conventions; the reference's librosa/resampy kernel is not pinned)
+//   awgn(snr)                 (:99-125)     per-waveform power, Philox/Box-Muller noise
+//   low_pass_filter           (:21-30)      butter(8, 0.5) + filtfilt(odd padding 27, steady-state zi), evaluated
+//                                           as the equivalent pair of causal / anti-causal 128-tap FIR passes
+//                                           (impulse response truncated at 5e-12) -> fully parallel
+//   amplitude_scaling(factor) (:55-58)
+// One workgroup owns one waveform and keeps it in LDS through the whole chain (8002 samples = 32 KB), so
+// the chain costs one HBM read and one HBM write per sample.  Every stage is linear except AWGN's
+// signal-dependent sigma; the backward kernel applies the exact adjoints in reverse order.
+#include "common.h"
+#include "../../include/wm_kernels.h"
+
+namespace {
+
+constexpr int NT = 512;
+constexpr int PADLEN = 27;                 // scipy filtfilt default: 3 * max(len(a), len(b)) = 3 * 9
+constexpr int RS_HALF = 20;                // resample_poly half length for rate 2
+constexpr int BUF = 8064 + 64;
+
+struct Bufs { float* a; float* b; float* c; };
+
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) s += red[i];
+  return s;
+}
+
+// out[m] = sum_d h[20+d] * in[2m - d]                     (decimate by 2)
+__device__ __forceinline__ void rs_down(const float* in, float* out, const float* h, int L, int Ld, int tid) {
+  for (int m = tid; m < Ld; m += NT) {
+    float acc = 0.f;
+#pragma unroll
+    for (int d = -RS_HALF; d <= RS_HALF; ++d) {
+      const int i = 2 * m - d;
+      if (i >= 0 && i < L) acc += h[RS_HALF + d] * in[i];
+    }
+    out[m] = acc;
+  }
+}
+// out[n] = 2 * sum_m h[20 + n - 2m] * in[m]               (interpolate by 2)
+__device__ __forceinline__ void rs_up(const float* in, float* out, const float* h, int L, int Ld, int tid) {
+  for (int n = tid; n < L; n += NT) {
+    float acc = 0.f;
+    const int mlo = (n - RS_HALF + 1) >> 1;                // ceil((n-20)/2)
+    for (int m = mlo; 2 * m <= n + RS_HALF; ++m)
+      if (m >= 0 && m < Ld) acc += h[RS_HALF + n - 2 * m] * in[m];
+    out[n] = 2.0f * acc;
+  }
+}
+// adjoints
+__device__ __forceinline__ void rs_up_T(const float* g, float* out, const float* h, int L, int Ld, int tid) {
+  for (int m = tid; m < Ld; m += NT) {
+    float acc = 0.f;
+#pragma unroll
+    for (int d = -RS_HALF; d <= RS_HALF; ++d) {
+      const int n = 2 * m + d;
+      if (n >= 0 && n < L) acc += h[RS_HALF + d] * g[n];
+    }
+    out[m] = 2.0f * acc;
+  }
+}
+__device__ __forceinline__ void rs_down_T(const float* g, float* out, const float* h, int L, int Ld, int tid) {
+  for (int i = tid; i < L; i += NT) {
+    float acc = 0.f;
+    const int mlo = (i - RS_HALF + 1) >> 1;
+    for (int m = mlo; 2 * m <= i + RS_HALF; ++m)
+      if (m >= 0 && m < Ld) acc += h[RS_HALF + 2 * m - i] * g[m];
+    out[i] = acc;
+  }
+}
+
+// causal pass with constant left extension:  y[n] = sum_{j<=min(n,J-1)} h[j] e[n-j] + e[0] * tail[min(n,J-1)]
+__device__ __forceinline__ void fir_causal(const float* e, float* y, const float* h, const float* tail, int N, int J,
+                                           int tid) {
+  const float e0 = e[0];
+  for (int n = tid; n < N; n += NT) {
+    const int jm = n < J - 1 ? n : J - 1;
+    float acc = e0 * tail[jm];
+    for (int j = 0; j <= jm; ++j) acc += h[j] * e[n - j];
+    y[n] = acc;
+  }
+}
+// anti-causal pass with constant right extension
+__device__ __forceinline__ void fir_anticausal(const float* e, float* y, const float* h, const float* tail, int N,
+                                               int J, int tid) {
+  const float eN = e[N - 1];
+  for (int n = tid; n < N; n += NT) {
+    const int r = N - 1 - n, jm = r < J - 1 ? r : J - 1;
+    float acc = eN * tail[jm];
+    for (int j = 0; j <= jm; ++j) acc += h[j] * e[n + j];
+    y[n] = acc;
+  }
+}
+
+__device__ __forceinline__ void gauss4(uint64_t seed, uint64_t step, uint32_t row, uint32_t blk, float z[4]) {
+  uint32_t r[4];
+  philox4x32(blk, row, (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]), u3 = u01(r[3]);
+  const float m0 = sqrtf(-2.0f * logf(u0)), m1 = sqrtf(-2.0f * logf(u2));
+  float s, c;
+  sincospif(2.0f * u1, &s, &c); z[0] = m0 * c; z[1] = m0 * s;
+  sincospif(2.0f * u3, &s, &c); z[2] = m1 * c; z[3] = m1 * s;
+}
+
+__global__ __launch_bounds__(NT) void attack_fwd_kernel(const WmAttack a, const float* __restrict__ wave,
+                                                        float* __restrict__ out, float* __restrict__ sigma_out,
+                                                        int L) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* A = sm; float* Bf = sm + BUF; float* hs = sm + 2 * BUF;   // hs: lp_h[J] | tail[J] | rs_h[41] | red[8]
+  const int tid = threadIdx.x, row = blockIdx.x, J = a.lp_n;
+  float* tails = hs + J; float* rsh = hs + 2 * J; float* red = rsh + 48;
+  if (a.flags & 4) for (int i = tid; i < 2 * J; i += NT) hs[i] = a.lp_h[i];
+  if (a.flags & 1) for (int i = tid; i < 2 * RS_HALF + 1; i += NT) rsh[i] = a.rs_h[i];
+  for (int i = tid; i < L; i += NT) A[i] = wave[(int64_t)row * L + i];
+  __syncthreads();
+  float* cur = A; float* oth = Bf;
+  int off = 0;
+  if (a.flags & 1) {
+    const int Ld = (L + 1) / 2;
+    rs_down(cur, oth, rsh, L, Ld, tid);
+    __syncthreads();
+    rs_up(oth, cur, rsh, L, Ld, tid);
+    __syncthreads();
+  }
+  if (a.flags & 2) {
+    float p = 0.f;
+    for (int i = tid; i < L; i += NT) p += cur[i] * cur[i];
+    p = block_sum(p, red, tid) / (float)L;
+    const float sigma = sqrtf(p * exp10f(-a.snr_db * 0.1f));
+    const uint64_t step = a.step ? (uint64_t)*a.step : 0ull;
+    for (int q = tid; 4 * q < L; q += NT) {
+      float z[4];
+      gauss4(a.seed, step, (uint32_t)row, (uint32_t)q, z);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < L) cur[4 * q + e] += sigma * z[e];
+    }
+    if (tid == 0 && sigma_out) sigma_out[row] = sigma;
+    __syncthreads();
+  }
+  if (a.flags & 4) {
+    const int N = L + 2 * PADLEN;
+    const float x0 = cur[0], xl = cur[L - 1];
+    for (int q = tid; q < N; q += NT) {
+      float v;
+      if (q < PADLEN) v = 2.0f * x0 - cur[PADLEN - q];
+      else if (q < PADLEN + L) v = cur[q - PADLEN];
+      else v = 2.0f * xl - cur[L - 2 - (q - PADLEN - L)];
+      oth[q] = v;
+    }
+    __syncthreads();
+    fir_causal(oth, cur, hs, tails, N, J, tid);
+    __syncthreads();
+    fir_anticausal(cur, oth, hs, tails, N, J, tid);
+    __syncthreads();
+    float* t = cur; cur = oth; oth = t;
+    off = PADLEN;
+  }
+  const float amp = (a.flags & 8) ? a.amp : 1.0f;
+  for (int i = tid; i < L; i += NT) out[(int64_t)row * L + i] = amp * cur[off + i];
+}
+
+__global__ __launch_bounds__(NT) void attack_bwd_kernel(const WmAttack a, const float* __restrict__ wave,
+                                                        const float* __restrict__ dout,
+                                                        const float* __restrict__ sigma_in,
+                                                        float* __restrict__ dwave, int L) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* A = sm; float* Bf = sm + BUF; float* Cx = sm + 2 * BUF; float* hs = sm + 3 * BUF;
+  const int tid = threadIdx.x, row = blockIdx.x, J = a.lp_n;
+  float* tails = hs + J; float* rsh = hs + 2 * J; float* red = rsh + 48;
+  if (a.flags & 4) for (int i = tid; i < 2 * J; i += NT) hs[i] = a.lp_h[i];
+  if (a.flags & 1) for (int i = tid; i < 2 * RS_HALF + 1; i += NT) rsh[i] = a.rs_h[i];
+  const int Ld = (L + 1) / 2;
+  // x1 = input of the AWGN stage (needed for d sigma / d x)
+  if (a.flags & 2) {
+    for (int i = tid; i < L; i += NT) Cx[i] = wave[(int64_t)row * L + i];
+    __syncthreads();
+    if (a.flags & 1) {
+      rs_down(Cx, A, rsh, L, Ld, tid);
+      __syncthreads();
+      rs_up(A, Cx, rsh, L, Ld, tid);
+    }
+  }
+  __syncthreads();
+  const float amp = (a.flags & 8) ? a.amp : 1.0f;
+  float* g = A; float* oth = Bf;
+  if (a.flags & 4) {
+    const int N = L + 2 * PADLEN;
+    for (int q = tid; q < N; q += NT)
+      g[q] = (q >= PADLEN && q < PADLEN + L) ? amp * dout[(int64_t)row * L + q - PADLEN] : 0.f;
+    __syncthreads();
+    // adjoint of the anti-causal pass: causal correlation + tail term onto the last sample
+    for (int m = tid; m < N; m += NT) {
+      const int jm = m < J - 1 ? m : J - 1;
+      float acc = 0.f;
+      for (int j = 0; j <= jm; ++j) acc += hs[j] * g[m - j];
+      oth[m] = acc;
+    }
+    float t2 = 0.f;
+    for (int r = tid; r < J && r < N; r += NT) t2 += tails[r] * g[N - 1 - r];
+    t2 = block_sum(t2, red, tid);
+    // samples further than J-1 from the end all see tail[J-1]
+    float t2b = 0.f;
+    for (int n = tid; n < N - J; n += NT) t2b += g[n];
+    t2b = block_sum(t2b, red, tid) * tails[J - 1];
+    if (tid == 0) oth[N - 1] += t2 + t2b;
+    __syncthreads();
+    // adjoint of the causal pass
+    for (int m = tid; m < N; m += NT) {
+      const int r = N - 1 - m, jm = r < J - 1 ? r : J - 1;
+      float acc = 0.f;
+      for (int j = 0; j <= jm; ++j) acc += hs[j] * oth[m + j];
+      g[m] = acc;
+    }
+    float t1 = 0.f;
+    for (int n = tid; n < J && n < N; n += NT) t1 += tails[n] * oth[n];
+    t1 = block_sum(t1, red, tid);
+    float t1b = 0.f;
+    for (int n = J + tid; n < N; n += NT) t1b += oth[n];
+    t1b = block_sum(t1b, red, tid) * tails[J - 1];
+    if (tid == 0) g[0] += t1 + t1b;
+    __syncthreads();
+    // adjoint of the odd extension
+    float sl = 0.f, sr = 0.f;
+    if (tid < PADLEN) { sl = g[tid]; sr = g[PADLEN + L + tid]; }
+    sl = block_sum(sl, red, tid);
+    sr = block_sum(sr, red, tid);
+    for (int i = tid; i < L; i += NT) {
+      float v = g[PADLEN + i];
+      if (i == 0) v += 2.0f * sl;
+      if (i >= 1 && i <= PADLEN) v -= g[PADLEN - i];
+      if (i == L - 1) v += 2.0f * sr;
+      if (i >= L - 1 - PADLEN && i <= L - 2) v -= g[PADLEN + L + (L - 2 - i)];
+      oth[i] = v;
+    }
+    __syncthreads();
+    float* t = g; g = oth; oth = t;
+  } else {
+    for (int i = tid; i < L; i += NT) g[i] = amp * dout[(int64_t)row * L + i];
+    __syncthreads();
+  }
+  if (a.flags & 2) {
+    const float sigma = sigma_in[row];
+    const uint64_t step = a.step ? (uint64_t)*a.step : 0ull;
+    float dot = 0.f;
+    for (int q = tid; 4 * q < L; q += NT) {
+      float z[4];
+      gauss4(a.seed, step, (uint32_t)row, (uint32_t)q, z);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < L) dot += g[4 * q + e] * z[e];
+    }
+    dot = block_sum(dot, red, tid);
+    const float k = sigma > 0.f ? dot * exp10f(-a.snr_db * 0.1f) / ((float)L * sigma) : 0.f;
+    for (int i = tid; i < L; i += NT) g[i] += k * Cx[i];
+    __syncthreads();
+  }
+  if (a.flags & 1) {
+    rs_up_T(g, oth, rsh, L, Ld, tid);
+    __syncthreads();
+    rs_down_T(oth, g, rsh, L, Ld, tid);
+    __syncthreads();
+  }
+  for (int i = tid; i < L; i += NT) dwave[(int64_t)row * L + i] = g[i];
+}
+
+bool args_ok(const WmAttack* a, int B, int L) {
+  if (!a || B <= 0 || L < 64 || L + 2 * PADLEN > BUF) return false;
+  if ((a->flags & 4) && (!a->lp_h || a->lp_n < 2 || a->lp_n > 256)) return false;
+  if ((a->flags & 1) && (!a->rs_h || a->rs_n != 2 * RS_HALF + 1)) return false;
+  return true;
+}
+size_t smem_bytes(int nbuf, int J) { return sizeof(float) * ((size_t)nbuf * BUF + 2 * J + 48 + 16); }
+
+}  // namespace
+
+extern "C" int wm_attack_fwd(const WmAttack* a, const float* wave, float* out, float* sigma_out, int32_t B,
+                             int32_t L, void* stream) {
+  if (!args_ok(a, B, L) || !wave || !out) return WM_EINVAL;
+  if ((a->flags & 2) && !sigma_out) return WM_EINVAL;
+  const size_t sm = smem_bytes(2, a->lp_n > 0 ? a->lp_n : 1);
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attack_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)smem_bytes(2, 256));
+    done = true;
+  }
+  hipLaunchKernelGGL(attack_fwd_kernel, dim3(B), dim3(NT), sm, static_cast<hipStream_t>(stream), *a, wave, out,
+                     sigma_out, L);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int wm_attack_bwd(const WmAttack* a, const float* wave, const float* dout, const float* sigma,
+                             float* dwave, int32_t B, int32_t L, void* stream) {
+  if (!args_ok(a, B, L) || !wave || !dout || !dwave) return WM_EINVAL;
+  if ((a->flags & 2) && !sigma) return WM_EINVAL;
+  const size_t sm = smem_bytes(3, a->lp_n > 0 ? a->lp_n : 1);
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attack_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)smem_bytes(3, 256));
+    done = true;
+  }
+  hipLaunchKernelGGL(attack_bwd_kernel, dim3(B), dim3(NT), sm, static_cast<hipStream_t>(stream), *a, wave, dout, sigma,
+                     dwave, L);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}

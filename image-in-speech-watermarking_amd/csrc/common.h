@@ -1,0 +1,107 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the watermark train step.
+// Wave = 64 lanes everywhere; MFMA tiles are 32x32 (f32 accumulators, 16 regs per lane).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+#define WM_OK 0
+#define WM_EINVAL 22
+
+#define WM_CHECK_LAUNCH()                          \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return 1000 + (int)e__; \
+  } while (0)
+
+// ---- activations -------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) {          // nn.GELU() (erf form)
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  return cdf + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+// ---- LDS element types: float (exact "parity" mode) or bf16 (fast mode) --------------------
+template <typename LT> struct LdsT;
+template <> struct LdsT<float> {
+  static constexpr int PAD = 4;                       // row stride 36 floats = 144 B (16-B aligned)
+  __device__ static __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+  }
+  __device__ static __forceinline__ void store1(float* p, float a) { *p = a; }
+};
+template <> struct LdsT<__bf16> {
+  static constexpr int PAD = 8;                       // row stride 40 bf16 = 80 B (16-B aligned)
+  __device__ static __forceinline__ void store4(__bf16* p, float a, float b, float c, float d) {
+    bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    *reinterpret_cast<bf16x4*>(p) = v;
+  }
+  __device__ static __forceinline__ void store1(__bf16* p, float a) { *p = (__bf16)a; }
+};
+
+// acc(32x32) += A(32 x kcount) * B(kcount x 32).
+// a_row / b_row point at THIS LANE's row (tile_row0 + (lane & 31)) of a K-contiguous LDS image;
+// B is held "n-major" (Bs[n][k]) so both operands are read the same way.
+// f32: v_mfma_f32_32x32x2_f32, lane half h supplies k = 8s + 4h + j (any k permutation shared by
+//      A and B is a valid summation order).  bf16: v_mfma_f32_32x32x16_bf16, lane supplies
+//      k = 16s + 8h .. +7.
+template <typename LT>
+__device__ __forceinline__ void mma32(f32x16& acc, const LT* a_row, const LT* b_row, int kcount, int h);
+
+template <>
+__device__ __forceinline__ void mma32<float>(f32x16& acc, const float* a_row, const float* b_row,
+                                             int kcount, int h) {
+#pragma unroll 4
+  for (int k = 0; k < kcount; k += 8) {
+    const float4 a = *reinterpret_cast<const float4*>(a_row + k + 4 * h);
+    const float4 b = *reinterpret_cast<const float4*>(b_row + k + 4 * h);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+}
+template <>
+__device__ __forceinline__ void mma32<__bf16>(f32x16& acc, const __bf16* a_row, const __bf16* b_row,
+                                              int kcount, int h) {
+#pragma unroll 4
+  for (int k = 0; k < kcount; k += 16) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_row + k + 8 * h);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(b_row + k + 8 * h);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+}
+// C/D layout of every 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ int mma32_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Counter-based RNG (Philox4x32-10) so that random draws are a pure function of
+// (seed, step, stream, index): replayable inside hipGraphs and identical across ranks/launch shapes.
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (x >> 8) * (1.0f / 16777216.0f) + (0.5f / 16777216.0f); }

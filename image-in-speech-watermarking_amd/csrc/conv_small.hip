@@ -1,0 +1,259 @@
+// Direct convolutions for the thin layers at the model's edges, where channel counts are 1..64 and
+// an MFMA GEMM would be all padding: InputProj (model.py:814), OutputProj (:846), stft_layer (:2305),
+// ConvAutoencoder (:1700-1709), EncoderTransformerWM.conv2 (:1566) and the 2x2/16x8 max-pools.
+// One thread per output (forward / dX) or one workgroup per weight element (dW): these layers are
+// < 0.1 % of the step's FLOPs and bandwidth.
+#include "common.h"
+#include "../../include/wm_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float act_f(float v, int act) {
+  switch (act) {
+    case 1: return v > 0.f ? v : 0.f;
+    case 2: return v > 0.f ? v : 0.01f * v;
+    case 3: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+// derivative of the activation expressed through its OUTPUT y
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+  switch (act) {
+    case 1: return y > 0.f ? 1.f : 0.f;
+    case 2: return y > 0.f ? 1.f : 0.01f;
+    case 3: return y * (1.0f - y);
+    default: return 1.f;
+  }
+}
+__device__ __forceinline__ int64_t in_off(const WmConv& c, int b, int ci, int y, int x) {
+  return c.in_nhwc ? (((int64_t)b * c.H + y) * c.W + x) * c.Cin + ci : (((int64_t)b * c.Cin + ci) * c.H + y) * c.W + x;
+}
+__device__ __forceinline__ int64_t out_off(const WmConv& c, int b, int co, int y, int x) {
+  return c.out_nhwc ? (((int64_t)b * c.OH + y) * c.OW + x) * c.Cout + co
+                    : (((int64_t)b * c.Cout + co) * c.OH + y) * c.OW + x;
+}
+__device__ __forceinline__ void out_decode(const WmConv& c, int64_t idx, int& b, int& co, int& y, int& x) {
+  if (c.out_nhwc) {
+    co = (int)(idx % c.Cout); idx /= c.Cout; x = (int)(idx % c.OW); idx /= c.OW; y = (int)(idx % c.OH); b = (int)(idx / c.OH);
+  } else {
+    x = (int)(idx % c.OW); idx /= c.OW; y = (int)(idx % c.OH); idx /= c.OH; co = (int)(idx % c.Cout); b = (int)(idx / c.Cout);
+  }
+}
+__device__ __forceinline__ void in_decode(const WmConv& c, int64_t idx, int& b, int& ci, int& y, int& x) {
+  if (c.in_nhwc) {
+    ci = (int)(idx % c.Cin); idx /= c.Cin; x = (int)(idx % c.W); idx /= c.W; y = (int)(idx % c.H); b = (int)(idx / c.H);
+  } else {
+    x = (int)(idx % c.W); idx /= c.W; y = (int)(idx % c.H); idx /= c.H; ci = (int)(idx % c.Cin); b = (int)(idx / c.Cin);
+  }
+}
+
+__global__ void conv_fwd_kernel(const WmConv c, const float* __restrict__ x, const float* __restrict__ w,
+                                const float* __restrict__ bias, float* __restrict__ y, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int b, co, oy, ox;
+    out_decode(c, idx, b, co, oy, ox);
+    float acc = bias ? bias[co] : 0.f;
+    if (!c.transposed) {
+      for (int ci = 0; ci < c.Cin; ++ci)
+        for (int ky = 0; ky < c.KH; ++ky) {
+          const int iy = oy * c.SH - c.PH + ky;
+          if (iy < 0 || iy >= c.H) continue;
+          for (int kx = 0; kx < c.KW; ++kx) {
+            const int ix = ox * c.SW - c.PW + kx;
+            if (ix < 0 || ix >= c.W) continue;
+            acc += x[in_off(c, b, ci, iy, ix)] * w[((co * c.Cin + ci) * c.KH + ky) * c.KW + kx];
+          }
+        }
+    } else {
+      const int iy = oy / c.SH, ky = oy % c.SH, ix = ox / c.SW, kx = ox % c.SW;
+      for (int ci = 0; ci < c.Cin; ++ci)
+        acc += x[in_off(c, b, ci, iy, ix)] * w[((ci * c.Cout + co) * c.KH + ky) * c.KW + kx];
+    }
+    y[idx] = act_f(acc, c.act);
+  }
+}
+
+__global__ void conv_dx_kernel(const WmConv c, const float* __restrict__ w, const float* __restrict__ y,
+                               const float* __restrict__ dy, float* __restrict__ dx, int accumulate, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int b, ci, iy, ix;
+    in_decode(c, idx, b, ci, iy, ix);
+    float acc = 0.f;
+    if (!c.transposed) {
+      for (int ky = 0; ky < c.KH; ++ky) {
+        const int ty = iy + c.PH - ky;
+        if (ty < 0 || ty % c.SH) continue;
+        const int oy = ty / c.SH;
+        if (oy >= c.OH) continue;
+        for (int kx = 0; kx < c.KW; ++kx) {
+          const int tx = ix + c.PW - kx;
+          if (tx < 0 || tx % c.SW) continue;
+          const int ox = tx / c.SW;
+          if (ox >= c.OW) continue;
+          for (int co = 0; co < c.Cout; ++co) {
+            const int64_t o = out_off(c, b, co, oy, ox);
+            acc += dy[o] * act_grad_from_out(y[o], c.act) * w[((co * c.Cin + ci) * c.KH + ky) * c.KW + kx];
+          }
+        }
+      }
+    } else {
+      for (int co = 0; co < c.Cout; ++co)
+        for (int ky = 0; ky < c.KH; ++ky)
+          for (int kx = 0; kx < c.KW; ++kx) {
+            const int64_t o = out_off(c, b, co, iy * c.SH + ky, ix * c.SW + kx);
+            acc += dy[o] * act_grad_from_out(y[o], c.act) * w[((ci * c.Cout + co) * c.KH + ky) * c.KW + kx];
+          }
+    }
+    if (accumulate) dx[idx] += acc; else dx[idx] = acc;
+  }
+}
+
+// one workgroup per weight element (+ Cout extra workgroups for the bias)
+__global__ __launch_bounds__(256) void conv_dw_kernel(const WmConv c, const float* __restrict__ x,
+                                                      const float* __restrict__ y, const float* __restrict__ dy,
+                                                      float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[4];
+  const int nW = c.Cout * c.Cin * c.KH * c.KW;
+  const int e = blockIdx.x;
+  float acc = 0.f;
+  if (e < nW) {
+    int t = e;
+    const int kx = t % c.KW; t /= c.KW;
+    const int ky = t % c.KH; t /= c.KH;
+    int co, ci;
+    if (!c.transposed) { ci = t % c.Cin; co = t / c.Cin; } else { co = t % c.Cout; ci = t / c.Cout; }
+    if (!c.transposed) {
+      const int64_t n = (int64_t)c.B * c.OH * c.OW;
+      for (int64_t p = threadIdx.x; p < n; p += 256) {
+        const int ox = (int)(p % c.OW), oy = (int)((p / c.OW) % c.OH), b = (int)(p / ((int64_t)c.OW * c.OH));
+        const int iy = oy * c.SH - c.PH + ky, ix = ox * c.SW - c.PW + kx;
+        if (iy < 0 || iy >= c.H || ix < 0 || ix >= c.W) continue;
+        const int64_t o = out_off(c, b, co, oy, ox);
+        acc += dy[o] * act_grad_from_out(y[o], c.act) * x[in_off(c, b, ci, iy, ix)];
+      }
+    } else {
+      const int64_t n = (int64_t)c.B * c.H * c.W;
+      for (int64_t p = threadIdx.x; p < n; p += 256) {
+        const int ix = (int)(p % c.W), iy = (int)((p / c.W) % c.H), b = (int)(p / ((int64_t)c.W * c.H));
+        const int64_t o = out_off(c, b, co, iy * c.SH + ky, ix * c.SW + kx);
+        acc += dy[o] * act_grad_from_out(y[o], c.act) * x[in_off(c, b, ci, iy, ix)];
+      }
+    }
+  } else {
+    const int co = e - nW;
+    const int64_t n = (int64_t)c.B * c.OH * c.OW;
+    for (int64_t p = threadIdx.x; p < n; p += 256) {
+      const int ox = (int)(p % c.OW), oy = (int)((p / c.OW) % c.OH), b = (int)(p / ((int64_t)c.OW * c.OH));
+      const int64_t o = out_off(c, b, co, oy, ox);
+      acc += dy[o] * act_grad_from_out(y[o], c.act);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float s = (red[0] + red[1]) + (red[2] + red[3]);
+    if (e < nW) atomicAdd(dw + e, s); else if (db) atomicAdd(db + (e - nW), s);
+  }
+}
+
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int kh, int kw,
+                                   int64_t total) {
+  const int oh = H / kh, ow = W / kw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % ow), oy = (int)((idx / ow) % oh);
+    const int64_t pl = idx / ((int64_t)ow * oh);
+    const float* p = x + (pl * H + oy * kh) * W + ox * kw;
+    float m = -INFINITY;
+    for (int a = 0; a < kh; ++a)
+      for (int b = 0; b < kw; ++b) m = fmaxf(m, p[a * W + b]);
+    y[idx] = m;
+  }
+}
+// gradient goes to the FIRST maximal element of each (non-overlapping) window, as ATen does
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                   int H, int W, int kh, int kw, int accumulate, int64_t total) {
+  const int oh = H / kh, ow = W / kw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % ow), oy = (int)((idx / ow) % oh);
+    const int64_t pl = idx / ((int64_t)ow * oh);
+    const int64_t base = (pl * H + oy * kh) * W + ox * kw;
+    float m = -INFINITY;
+    int am = 0;
+    for (int a = 0; a < kh; ++a)
+      for (int b = 0; b < kw; ++b) {
+        const float v = x[base + a * W + b];
+        if (v > m) { m = v; am = a * kw + b; }
+      }
+    const float g = dy[idx];
+    for (int a = 0; a < kh; ++a)
+      for (int b = 0; b < kw; ++b) {
+        const float v = (a * kw + b == am) ? g : 0.f;
+        float* d = dx + base + a * W + b;
+        if (accumulate) *d += v; else *d = v;
+      }
+  }
+}
+
+inline unsigned grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+bool conv_ok(const WmConv* c) {
+  if (!c || c->B <= 0 || c->Cin <= 0 || c->Cout <= 0 || c->KH <= 0 || c->KW <= 0 || c->SH <= 0 || c->SW <= 0) return false;
+  if (c->transposed) {
+    return c->KH == c->SH && c->KW == c->SW && c->PH == 0 && c->PW == 0 && c->OH == c->H * c->SH && c->OW == c->W * c->SW;
+  }
+  return c->OH == (c->H + 2 * c->PH - c->KH) / c->SH + 1 && c->OW == (c->W + 2 * c->PW - c->KW) / c->SW + 1;
+}
+
+}  // namespace
+
+extern "C" int wm_conv_fwd(const WmConv* c, const float* x, const float* w, const float* b, float* y, void* stream) {
+  if (!conv_ok(c) || !x || !w || !y) return WM_EINVAL;
+  const int64_t total = (int64_t)c->B * c->Cout * c->OH * c->OW;
+  hipLaunchKernelGGL(conv_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), *c, x, w,
+                     b, y, total);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int wm_conv_bwd(const WmConv* c, const float* x, const float* w, const float* y, const float* dy,
+                           float* dx, int32_t dx_accumulate, float* dw, float* db, void* stream) {
+  if (!conv_ok(c) || !x || !w || !y || !dy) return WM_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dx) {
+    const int64_t total = (int64_t)c->B * c->Cin * c->H * c->W;
+    hipLaunchKernelGGL(conv_dx_kernel, dim3(grid_for(total)), dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate, total);
+    WM_CHECK_LAUNCH();
+  }
+  if (dw) {
+    const int nW = c->Cout * c->Cin * c->KH * c->KW;
+    hipLaunchKernelGGL(conv_dw_kernel, dim3(nW + (db ? c->Cout : 0)), dim3(256), 0, st, *c, x, y, dy, dw, db);
+    WM_CHECK_LAUNCH();
+  }
+  return WM_OK;
+}
+
+extern "C" int wm_maxpool_fwd(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t kh, int32_t kw,
+                              void* stream) {
+  if (!x || !y || planes <= 0 || kh <= 0 || kw <= 0 || H % kh || W % kw) return WM_EINVAL;
+  const int64_t total = (int64_t)planes * (H / kh) * (W / kw);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y,
+                     H, W, kh, kw, total);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_maxpool_bwd(const float* x, const float* dy, float* dx, int32_t planes, int32_t H, int32_t W,
+                              int32_t kh, int32_t kw, int32_t accumulate, void* stream) {
+  if (!x || !dy || !dx || planes <= 0 || kh <= 0 || kw <= 0 || H % kh || W % kw) return WM_EINVAL;
+  const int64_t total = (int64_t)planes * (H / kh) * (W / kw);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, dy,
+                     dx, H, W, kh, kw, accumulate, total);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}

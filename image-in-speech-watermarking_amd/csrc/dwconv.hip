@@ -1,0 +1,149 @@
+// LeFF depthwise 3x3 convolution on token-major activations [B, hw, hw, Ch] (reference
+// model.py:703-709: rearrange -> Conv2d(groups=Ch, k=3, p=1) -> GELU -> rearrange).  The token-major
+// layout makes the channel dim contiguous, so no b(hw)c <-> bchw transposes are materialised.
+// Input is linear1's PRE-activation; GELU is applied once per staged element (tile + halo in LDS).
+// Output is the pre-activation of the second GELU (applied by the consumer GEMM while staging).
+#include "common.h"
+#include "../../include/wm_kernels.h"
+
+namespace {
+
+constexpr int TP = 8;              // tile is TP x TP pixels
+constexpr int HP = TP + 2;         // with halo
+constexpr int TC = 64;             // channels per workgroup
+
+__device__ __forceinline__ void load_halo_tile(float* tile, const float* __restrict__ src, int b, int ty, int tx,
+                                               int hw, int Ch, int cbase, bool gelu, int tid) {
+  for (int idx = tid; idx < HP * HP * (TC / 4); idx += 256) {
+    const int pix = idx / (TC / 4), c4 = idx % (TC / 4);
+    const int ly = pix / HP, lx = pix % HP;
+    const int gy = ty * TP + ly - 1, gx = tx * TP + lx - 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gy >= 0 && gy < hw && gx >= 0 && gx < hw) {
+      v = *reinterpret_cast<const float4*>(src + (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4);
+      if (gelu) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+    }
+    *reinterpret_cast<float4*>(tile + pix * TC + 4 * c4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ h1, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ h2,
+                                                         int B, int hw, int Ch) {
+  __shared__ __attribute__((aligned(16))) float tile[HP * HP * TC];
+  const int tid = threadIdx.x, nt = hw / TP;
+  const int t = blockIdx.x, b = t / (nt * nt), tr = t - b * nt * nt, ty = tr / nt, tx = tr - ty * nt;
+  const int cbase = blockIdx.y * TC;
+  load_halo_tile(tile, h1, b, ty, tx, hw, Ch, cbase, true, tid);
+  const int c4 = tid & 15, pg = tid >> 4;
+  float wr[4][9], br[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    br[cc] = bias[cbase + 4 * c4 + cc];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[cc][k] = w[(cbase + 4 * c4 + cc) * 9 + k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int pix = pg * 4 + q, py = pix >> 3, px = pix & 7;
+    float o[4] = {br[0], br[1], br[2], br[3]};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const float4 a = *reinterpret_cast<const float4*>(tile + ((py + dy) * HP + px + dx) * TC + 4 * c4);
+        o[0] += wr[0][dy * 3 + dx] * a.x; o[1] += wr[1][dy * 3 + dx] * a.y;
+        o[2] += wr[2][dy * 3 + dx] * a.z; o[3] += wr[3][dy * 3 + dx] * a.w;
+      }
+    const int gy = ty * TP + py, gx = tx * TP + px;
+    *reinterpret_cast<float4*>(h2 + (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4) =
+        make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// dh1 = gelu'(h1) * sum_k w[k] * dh2[p - off_k];  dw[c][k] += sum_p dh2[p] * gelu(h1)[p + off_k]; db += sum_p dh2
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict__ h1, const float* __restrict__ dh2,
+                                                         const float* __restrict__ w, float* __restrict__ dh1,
+                                                         float* __restrict__ dw, float* __restrict__ db, int B,
+                                                         int hw, int Ch) {
+  __shared__ __attribute__((aligned(16))) float ta[HP * HP * TC];      // gelu(h1) with halo
+  __shared__ __attribute__((aligned(16))) float tg[HP * HP * TC];      // dh2 with halo
+  __shared__ float wacc[TC * 10];
+  const int tid = threadIdx.x, nt = hw / TP;
+  const int b = blockIdx.x / nt, ty = blockIdx.x % nt;
+  const int cbase = blockIdx.y * TC;
+  const int c4 = tid & 15, pg = tid >> 4;
+  float wr[4][9], aw[4][9], ab[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    ab[cc] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { wr[cc][k] = w[(cbase + 4 * c4 + cc) * 9 + k]; aw[cc][k] = 0.f; }
+  }
+  for (int i = tid; i < TC * 10; i += 256) wacc[i] = 0.f;
+  for (int tx = 0; tx < nt; ++tx) {
+    __syncthreads();
+    load_halo_tile(ta, h1, b, ty, tx, hw, Ch, cbase, true, tid);
+    load_halo_tile(tg, dh2, b, ty, tx, hw, Ch, cbase, false, tid);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pix = pg * 4 + q, py = pix >> 3, px = pix & 7;
+      const float4 gc = *reinterpret_cast<const float4*>(tg + ((py + 1) * HP + px + 1) * TC + 4 * c4);
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int k = dy * 3 + dx;
+          const float4 g = *reinterpret_cast<const float4*>(tg + ((py + 2 - dy) * HP + px + 2 - dx) * TC + 4 * c4);
+          o[0] += wr[0][k] * g.x; o[1] += wr[1][k] * g.y; o[2] += wr[2][k] * g.z; o[3] += wr[3][k] * g.w;
+          const float4 a = *reinterpret_cast<const float4*>(ta + ((py + dy) * HP + px + dx) * TC + 4 * c4);
+          aw[0][k] += gc.x * a.x; aw[1][k] += gc.y * a.y; aw[2][k] += gc.z * a.z; aw[3][k] += gc.w * a.w;
+        }
+      ab[0] += gc.x; ab[1] += gc.y; ab[2] += gc.z; ab[3] += gc.w;
+      const int gy = ty * TP + py, gx = tx * TP + px;
+      const int64_t off = (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4;
+      const float4 hv = *reinterpret_cast<const float4*>(h1 + off);
+      *reinterpret_cast<float4*>(dh1 + off) = make_float4(o[0] * gelu_grad_f(hv.x), o[1] * gelu_grad_f(hv.y),
+                                                           o[2] * gelu_grad_f(hv.z), o[3] * gelu_grad_f(hv.w));
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) atomicAdd(&wacc[(4 * c4 + cc) * 10 + k], aw[cc][k]);
+    atomicAdd(&wacc[(4 * c4 + cc) * 10 + 9], ab[cc]);
+  }
+  __syncthreads();
+  for (int i = tid; i < TC * 10; i += 256) {
+    const int c = i / 10, k = i % 10;
+    if (k < 9) atomicAdd(dw + (cbase + c) * 9 + k, wacc[i]);
+    else atomicAdd(db + cbase + c, wacc[i]);
+  }
+}
+
+bool ok(int B, int hw, int Ch) { return B > 0 && hw >= 8 && (hw & 7) == 0 && Ch >= 64 && (Ch & 63) == 0; }
+
+}  // namespace
+
+extern "C" int wm_dwconv_fwd(const float* h1, const float* w, const float* b, float* h2, int32_t B, int32_t hw,
+                             int32_t Ch, void* stream) {
+  if (!h1 || !w || !b || !h2 || !ok(B, hw, Ch)) return WM_EINVAL;
+  const int nt = hw / TP;
+  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(B * nt * nt, Ch / TC), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     h1, w, b, h2, B, hw, Ch);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int wm_dwconv_bwd(const float* h1, const float* dh2, const float* w, float* dh1, float* dw, float* db,
+                             int32_t B, int32_t hw, int32_t Ch, void* stream) {
+  if (!h1 || !dh2 || !w || !dh1 || !dw || !db || !ok(B, hw, Ch)) return WM_EINVAL;
+  const int nt = hw / TP;
+  hipLaunchKernelGGL(dwconv_bwd_kernel, dim3(B * nt, Ch / TC), dim3(256), 0, static_cast<hipStream_t>(stream), h1,
+                     dh2, w, dh1, dw, db, B, hw, Ch);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}

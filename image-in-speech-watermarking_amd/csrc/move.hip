@@ -1,0 +1,230 @@
+// Pure data-movement kernels around the MFMA GEMMs: im2col / col2im for Downsample (conv 4x4 s2 p1,
+// reference model.py:763), pixel (un)shuffle for Upsample (ConvTranspose 2x2 s2, model.py:789), the
+// skip-connection channel concat (model.py:1225) and a generic strided 3-D gather used for the
+// weight re-layouts.  All HBM-bound: float4 per lane, channel dim contiguous.
+#include "common.h"
+#include "../../include/wm_kernels.h"
+
+namespace {
+
+__global__ void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int hw, int C,
+                              int64_t total) {
+  const int c4n = C / 4, oh = hw / 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % c4n);
+    const int tap = (int)((idx / c4n) % 16);
+    const int64_t m = idx / ((int64_t)c4n * 16);
+    const int j = (int)(m % oh), i = (int)((m / oh) % oh), b = (int)(m / ((int64_t)oh * oh));
+    const int yy = 2 * i - 1 + (tap >> 2), xx = 2 * j - 1 + (tap & 3);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (yy >= 0 && yy < hw && xx >= 0 && xx < hw)
+      v = *reinterpret_cast<const float4*>(x + (((int64_t)b * hw + yy) * hw + xx) * C + 4 * c4);
+    *reinterpret_cast<float4*>(cols + (m * 16 + tap) * C + 4 * c4) = v;
+  }
+}
+
+__global__ void col2im_kernel(const float* __restrict__ dcols, float* __restrict__ dx, int B, int hw, int C,
+                              int64_t total) {
+  const int c4n = C / 4, oh = hw / 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % c4n);
+    const int64_t pix = idx / c4n;
+    const int xx = (int)(pix % hw), yy = (int)((pix / hw) % hw), b = (int)(pix / ((int64_t)hw * hw));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int i = ((yy + 1) >> 1) - a, di = yy + 1 - 2 * i;
+      if (i < 0 || i >= oh || di > 3) continue;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int j = ((xx + 1) >> 1) - c, dj = xx + 1 - 2 * j;
+        if (j < 0 || j >= oh || dj > 3) continue;
+        const int64_t m = ((int64_t)b * oh + i) * oh + j;
+        const float4 v = *reinterpret_cast<const float4*>(dcols + (m * 16 + di * 4 + dj) * C + 4 * c4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    *reinterpret_cast<float4*>(dx + pix * C + 4 * c4) = acc;
+  }
+}
+
+// y4[m, t*Co + o] (+ bias[o]) -> dst[b, 2i+di, 2j+dj, c0+o]
+__global__ void shuffle_kernel(const float* __restrict__ y4, const float* __restrict__ bias, float* __restrict__ dst,
+                               int B, int hw, int Co, int64_t ldd, int c0, int64_t total) {
+  const int o4n = Co / 4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int o4 = (int)(idx % o4n);
+    const int t = (int)((idx / o4n) % 4);
+    const int64_t m = idx / ((int64_t)o4n * 4);
+    const int j = (int)(m % hw), i = (int)((m / hw) % hw), b = (int)(m / ((int64_t)hw * hw));
+    float4 v = *reinterpret_cast<const float4*>(y4 + (m * 4 + t) * Co + 4 * o4);
+    if (bias) {
+      const float4 bb = *reinterpret_cast<const float4*>(bias + 4 * o4);
+      v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+    }
+    const int64_t row = ((int64_t)b * 2 * hw + 2 * i + (t >> 1)) * 2 * hw + 2 * j + (t & 1);
+    *reinterpret_cast<float4*>(dst + row * ldd + c0 + 4 * o4) = v;
+  }
+}
+
+__global__ void unshuffle_kernel(const float* __restrict__ dsrc, float* __restrict__ dy4, int B, int hw, int Co,
+                                 int64_t lds, int c0, int64_t total) {
+  const int o4n = Co / 4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int o4 = (int)(idx % o4n);
+    const int t = (int)((idx / o4n) % 4);
+    const int64_t m = idx / ((int64_t)o4n * 4);
+    const int j = (int)(m % hw), i = (int)((m / hw) % hw), b = (int)(m / ((int64_t)hw * hw));
+    const int64_t row = ((int64_t)b * 2 * hw + 2 * i + (t >> 1)) * 2 * hw + 2 * j + (t & 1);
+    *reinterpret_cast<float4*>(dy4 + (m * 4 + t) * Co + 4 * o4) =
+        *reinterpret_cast<const float4*>(dsrc + row * lds + c0 + 4 * o4);
+  }
+}
+
+__global__ void copy_cols_kernel(const float* __restrict__ src, int64_t lds, int s0, float* __restrict__ dst,
+                                 int64_t ldd, int c0, int64_t rows, int C, int acc, int64_t total) {
+  const int c4n = C / 4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % c4n);
+    const int64_t r = idx / c4n;
+    float4 v = *reinterpret_cast<const float4*>(src + r * lds + s0 + 4 * c4);
+    float* d = dst + r * ldd + c0 + 4 * c4;
+    if (acc) {
+      const float4 o = *reinterpret_cast<const float4*>(d);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *reinterpret_cast<float4*>(d) = v;
+  }
+}
+
+__global__ void strided3_kernel(const float* __restrict__ in, float* __restrict__ out, int n0, int n1, int n2,
+                                int64_t si0, int64_t si1, int64_t si2, int64_t so0, int64_t so1, int64_t so2,
+                                int atomic) {
+  const int64_t total = (int64_t)n0 * n1 * n2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i2 = (int)(idx % n2), i1 = (int)((idx / n2) % n1), i0 = (int)(idx / ((int64_t)n1 * n2));
+    const float v = in[i0 * si0 + i1 * si1 + i2 * si2];
+    float* d = out + i0 * so0 + i1 * so1 + i2 * so2;
+    if (atomic) atomicAdd(d, v); else *d = v;
+  }
+}
+
+__global__ void axpbyz_kernel(float* __restrict__ out, float a, const float* __restrict__ x, float b,
+                              const float* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+// Payload feature [B,4,64] tiled (1,16,8) into the first 512 channels of the bottleneck concat
+// [B,64,1024] (reference model.py:2389,2411) and the matching gradient fold.
+__global__ void msg_expand_fwd_kernel(const float* __restrict__ feat, float* __restrict__ dst, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % 512), r = (int)((idx / 512) % 64);
+    const int64_t b = idx / (512 * 64);
+    dst[(b * 64 + r) * 1024 + c] = feat[b * 256 + (r & 3) * 64 + (c & 63)];
+  }
+}
+__global__ void msg_expand_bwd_kernel(const float* __restrict__ dcat, float* __restrict__ dfeat, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(idx % 64), a = (int)((idx / 64) % 4);
+    const int64_t b = idx / 256;
+    float acc = 0.f;
+    for (int rr = 0; rr < 16; ++rr)
+      for (int cc = 0; cc < 8; ++cc) acc += dcat[(b * 64 + rr * 4 + a) * 1024 + cc * 64 + e];
+    dfeat[idx] += acc;
+  }
+}
+
+inline unsigned grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int wm_im2col_4x4s2(const float* x, float* cols, int32_t B, int32_t hw, int32_t C, void* stream) {
+  if (!x || !cols || B <= 0 || hw < 2 || (hw & 1) || C < 4 || (C & 3)) return WM_EINVAL;
+  const int64_t total = (int64_t)B * (hw / 2) * (hw / 2) * 16 * (C / 4);
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, cols,
+                     B, hw, C, total);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_col2im_4x4s2(const float* dcols, float* dx, int32_t B, int32_t hw, int32_t C, void* stream) {
+  if (!dcols || !dx || B <= 0 || hw < 2 || (hw & 1) || C < 4 || (C & 3)) return WM_EINVAL;
+  const int64_t total = (int64_t)B * hw * hw * (C / 4);
+  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), dcols, dx,
+                     B, hw, C, total);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_pixel_shuffle2(const float* y4, const float* bias, float* dst, int32_t B, int32_t hw, int32_t Co,
+                                 int64_t ldd, int32_t c0, void* stream) {
+  if (!y4 || !dst || B <= 0 || hw <= 0 || Co < 4 || (Co & 3) || (ldd & 3) || (c0 & 3) || !al16(dst)) return WM_EINVAL;
+  const int64_t total = (int64_t)B * hw * hw * 4 * (Co / 4);
+  hipLaunchKernelGGL(shuffle_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), y4, bias,
+                     dst, B, hw, Co, ldd, c0, total);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_pixel_unshuffle2(const float* dsrc, float* dy4, int32_t B, int32_t hw, int32_t Co, int64_t lds,
+                                   int32_t c0, void* stream) {
+  if (!dsrc || !dy4 || B <= 0 || hw <= 0 || Co < 4 || (Co & 3) || (lds & 3) || (c0 & 3) || !al16(dsrc))
+    return WM_EINVAL;
+  const int64_t total = (int64_t)B * hw * hw * 4 * (Co / 4);
+  hipLaunchKernelGGL(unshuffle_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), dsrc,
+                     dy4, B, hw, Co, lds, c0, total);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_copy_cols(const float* src, int64_t lds, int32_t s0, float* dst, int64_t ldd, int32_t c0,
+                            int64_t rows, int32_t C, int32_t accumulate, void* stream) {
+  if (!src || !dst || rows <= 0 || C < 4 || (C & 3) || (lds & 3) || (ldd & 3) || (s0 & 3) || (c0 & 3) ||
+      !al16(src) || !al16(dst))
+    return WM_EINVAL;
+  const int64_t total = rows * (C / 4);
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds,
+                     s0, dst, ldd, c0, rows, C, accumulate, total);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_strided3(const float* in, float* out, int32_t n0, int32_t n1, int32_t n2, int64_t si0, int64_t si1,
+                           int64_t si2, int64_t so0, int64_t so1, int64_t so2, int32_t atomic, void* stream) {
+  if (!in || !out || n0 <= 0 || n1 <= 0 || n2 <= 0) return WM_EINVAL;
+  hipLaunchKernelGGL(strided3_kernel, dim3(grid_for((int64_t)n0 * n1 * n2)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, out, n0, n1, n2, si0, si1, si2, so0, so1, so2, atomic);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_axpbyz(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream) {
+  if (!out || !x || n <= 0) return WM_EINVAL;
+  hipLaunchKernelGGL(axpbyz_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), out, a, x, b, y,
+                     n);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_msg_expand_fwd(const float* feat, float* dst, int32_t B, void* stream) {
+  if (!feat || !dst || B <= 0) return WM_EINVAL;
+  const int64_t total = (int64_t)B * 64 * 512;
+  hipLaunchKernelGGL(msg_expand_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), feat,
+                     dst, total);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_msg_expand_bwd(const float* dcat, float* dfeat, int32_t B, void* stream) {
+  if (!dcat || !dfeat || B <= 0) return WM_EINVAL;
+  const int64_t total = (int64_t)B * 256;
+  hipLaunchKernelGGL(msg_expand_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), dcat,
+                     dfeat, total);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}

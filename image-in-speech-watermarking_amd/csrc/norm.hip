@@ -1,0 +1,248 @@
+// LayerNorm over the channel dim of token-major activations [rows, C], fused with the window
+// "modulator" add of the decoder blocks (reference model.py:982,1017 and :996-997).
+// A row is handled by L = min(64, C/4) lanes holding float4 slices (coalesced 16-B accesses);
+// statistics are reduced with in-wave xor shuffles, no LDS.
+#include "common.h"
+#include "../../include/wm_kernels.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+
+__device__ __forceinline__ int window_pos(int64_t row, int hw, int shift) {
+  const int t = (int)(row % ((int64_t)hw * hw));
+  const int yy = t / hw, xx = t - yy * hw;
+  const int i = (yy - shift + hw) % hw, j = (xx - shift + hw) % hw;
+  return (i & 7) * 8 + (j & 7);
+}
+
+template <int L>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = L / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ mod,
+                                                     float* __restrict__ y, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int64_t rows, int hw, int shift) {
+  constexpr int L = (C / 4 < 64) ? C / 4 : 64;
+  constexpr int V = C / (4 * L);
+  constexpr int RPW = 64 / L;                       // rows per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % L, rg = lane / L;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * RPW + rg;
+  if (row >= rows) return;                          // whole lane groups exit together
+  float4 v[V];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    v[q] = *reinterpret_cast<const float4*>(x + row * C + (q * L + sub) * 4);
+    s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+  }
+  const float mu = group_sum<L>(s) * (1.0f / C);
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    const float a = v[q].x - mu, b = v[q].y - mu, c = v[q].z - mu, d = v[q].w - mu;
+    ss += (a * a + b * b) + (c * c + d * d);
+  }
+  const float rs = 1.0f / sqrtf(group_sum<L>(ss) * (1.0f / C) + LN_EPS);
+  const float* mrow = mod ? mod + (int64_t)window_pos(row, hw, shift) * C : nullptr;
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    const int c = (q * L + sub) * 4;
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+    float4 o;
+    o.x = (v[q].x - mu) * rs * gm.x + bt.x;
+    o.y = (v[q].y - mu) * rs * gm.y + bt.y;
+    o.z = (v[q].z - mu) * rs * gm.z + bt.z;
+    o.w = (v[q].w - mu) * rs * gm.w + bt.w;
+    if (mrow) {
+      const float4 mm = *reinterpret_cast<const float4*>(mrow + c);
+      o.x += mm.x; o.y += mm.y; o.z += mm.z; o.w += mm.w;
+    }
+    *reinterpret_cast<float4*>(y + row * C + c) = o;
+  }
+  if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.
+// dgamma / dbeta: per-lane partial sums over the rows this wave visits, then LDS + atomics.
+template <int C>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int64_t rows) {
+  constexpr int L = (C / 4 < 64) ? C / 4 : 64;
+  constexpr int V = C / (4 * L);
+  constexpr int RPW = 64 / L;
+  __shared__ float red[2][4][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % L, rg = lane / L;
+  float4 ag[V], ab[V], gm[V];
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    ag[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    gm[q] = *reinterpret_cast<const float4*>(gamma + (q * L + sub) * 4);
+  }
+  const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+  for (int64_t row = ((int64_t)blockIdx.x * 4 + wave) * RPW + rg; row < rows; row += stride) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[V], g[V];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const int c = (q * L + sub) * 4;
+      const float4 xv = *reinterpret_cast<const float4*>(x + row * C + c);
+      const float4 dv = *reinterpret_cast<const float4*>(dy + row * C + c);
+      xh[q] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+      g[q] = make_float4(dv.x * gm[q].x, dv.y * gm[q].y, dv.z * gm[q].z, dv.w * gm[q].w);
+      s1 += (g[q].x + g[q].y) + (g[q].z + g[q].w);
+      s2 += (g[q].x * xh[q].x + g[q].y * xh[q].y) + (g[q].z * xh[q].z + g[q].w * xh[q].w);
+      ag[q].x += dv.x * xh[q].x; ag[q].y += dv.y * xh[q].y; ag[q].z += dv.z * xh[q].z; ag[q].w += dv.w * xh[q].w;
+      ab[q].x += dv.x; ab[q].y += dv.y; ab[q].z += dv.z; ab[q].w += dv.w;
+    }
+    s1 = group_sum<L>(s1) * (1.0f / C);
+    s2 = group_sum<L>(s2) * (1.0f / C);
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const int c = (q * L + sub) * 4;
+      float4 o;
+      o.x = rs * (g[q].x - s1 - xh[q].x * s2);
+      o.y = rs * (g[q].y - s1 - xh[q].y * s2);
+      o.z = rs * (g[q].z - s1 - xh[q].z * s2);
+      o.w = rs * (g[q].w - s1 - xh[q].w * s2);
+      if (dres) {
+        const float4 dr = *reinterpret_cast<const float4*>(dres + row * C + c);
+        o.x += dr.x; o.y += dr.y; o.z += dr.z; o.w += dr.w;
+      }
+      *reinterpret_cast<float4*>(dx + row * C + c) = o;
+    }
+  }
+  // fold the RPW row groups of a wave (lanes sub, sub+L, ...) then the 4 waves
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+#pragma unroll
+    for (int o = L; o < 64; o <<= 1) {
+      ag[q].x += __shfl_xor(ag[q].x, o); ag[q].y += __shfl_xor(ag[q].y, o);
+      ag[q].z += __shfl_xor(ag[q].z, o); ag[q].w += __shfl_xor(ag[q].w, o);
+      ab[q].x += __shfl_xor(ab[q].x, o); ab[q].y += __shfl_xor(ab[q].y, o);
+      ab[q].z += __shfl_xor(ab[q].z, o); ab[q].w += __shfl_xor(ab[q].w, o);
+    }
+    if (rg == 0) {
+      const int c = (q * L + sub) * 4;
+      *reinterpret_cast<float4*>(&red[0][wave][c]) = ag[q];
+      *reinterpret_cast<float4*>(&red[1][wave][c]) = ab[q];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+    atomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+  }
+}
+
+// dmod[pos, c] += sum over windows of dy[token(window, pos), c]
+__global__ __launch_bounds__(256) void ln_dmod_kernel(const float* __restrict__ dy, float* __restrict__ dmod,
+                                                      int B, int hw, int C, int shift, int wchunk) {
+  __shared__ float4 red[256];
+  const int pos = blockIdx.x, py = pos >> 3, px = pos & 7;
+  const int c4n = C / 4, nsub = 256 / c4n;
+  const int c4 = threadIdx.x % c4n, wsub = threadIdx.x / c4n;
+  const int nw = hw / 8, nwin = B * nw * nw;
+  const int w0 = blockIdx.y * wchunk, w1 = min(nwin, w0 + wchunk);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int w = w0 + wsub; w < w1; w += nsub) {
+    const int b = w / (nw * nw), wr = w - b * nw * nw, wy = wr / nw, wx = wr - wy * nw;
+    const int yy = (wy * 8 + py + shift) % hw, xx = (wx * 8 + px + shift) % hw;
+    const int64_t row = (int64_t)b * hw * hw + yy * hw + xx;
+    const float4 v = *reinterpret_cast<const float4*>(dy + row * C + c4 * 4);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (wsub == 0) {
+    for (int s = 1; s < nsub; ++s) {
+      const float4 v = red[s * c4n + c4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float* d = dmod + (int64_t)pos * C + c4 * 4;
+    atomicAdd(d + 0, acc.x); atomicAdd(d + 1, acc.y); atomicAdd(d + 2, acc.z); atomicAdd(d + 3, acc.w);
+  }
+}
+
+template <int C>
+int ln_fwd_launch(const float* x, const float* g, const float* b, const float* mod, float* y, float* mean,
+                  float* rstd, int64_t rows, int hw, int shift, hipStream_t st) {
+  constexpr int L = (C / 4 < 64) ? C / 4 : 64;
+  constexpr int RPB = 4 * (64 / L);
+  const int64_t blocks = (rows + RPB - 1) / RPB;
+  hipLaunchKernelGGL((ln_fwd_kernel<C>), dim3((unsigned)blocks), dim3(256), 0, st, x, g, b, mod, y, mean, rstd,
+                     rows, hw, shift);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+template <int C>
+int ln_bwd_launch(const float* dy, const float* x, const float* g, const float* mean, const float* rstd,
+                  const float* dres, float* dx, float* dg, float* db, int64_t rows, hipStream_t st) {
+  constexpr int L = (C / 4 < 64) ? C / 4 : 64;
+  constexpr int RPB = 4 * (64 / L);
+  int64_t blocks = (rows + RPB - 1) / RPB;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL((ln_bwd_kernel<C>), dim3((unsigned)blocks), dim3(256), 0, st, dy, x, g, mean, rstd, dres,
+                     dx, dg, db, rows);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+}  // namespace
+
+extern "C" int wm_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* modulator,
+                                float* y, float* mean, float* rstd, int64_t rows, int32_t C, int32_t hw,
+                                int32_t shift, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return WM_EINVAL;
+  if (modulator && (hw <= 0 || (hw & 7) || rows % ((int64_t)hw * hw))) return WM_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (C) {
+    case 32: return ln_fwd_launch<32>(x, gamma, beta, modulator, y, mean, rstd, rows, hw, shift, st);
+    case 64: return ln_fwd_launch<64>(x, gamma, beta, modulator, y, mean, rstd, rows, hw, shift, st);
+    case 128: return ln_fwd_launch<128>(x, gamma, beta, modulator, y, mean, rstd, rows, hw, shift, st);
+    case 256: return ln_fwd_launch<256>(x, gamma, beta, modulator, y, mean, rstd, rows, hw, shift, st);
+    case 512: return ln_fwd_launch<512>(x, gamma, beta, modulator, y, mean, rstd, rows, hw, shift, st);
+    default: return WM_EINVAL;
+  }
+}
+
+extern "C" int wm_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                                float* dmod, int64_t rows, int32_t C, int32_t hw, int32_t shift, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return WM_EINVAL;
+  if (dmod && (hw <= 0 || (hw & 7) || rows % ((int64_t)hw * hw) || C < 64 || C > 1024)) return WM_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc;
+  switch (C) {
+    case 32: rc = ln_bwd_launch<32>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
+    case 64: rc = ln_bwd_launch<64>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
+    case 128: rc = ln_bwd_launch<128>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
+    case 256: rc = ln_bwd_launch<256>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
+    case 512: rc = ln_bwd_launch<512>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
+    default: return WM_EINVAL;
+  }
+  if (rc) return rc;
+  if (dmod) {
+    const int B = (int)(rows / ((int64_t)hw * hw));
+    const int nwin = B * (hw / 8) * (hw / 8);
+    int chunks = (nwin + 63) / 64;
+    if (chunks > 32) chunks = 32;
+    const int wchunk = (nwin + chunks - 1) / chunks;
+    hipLaunchKernelGGL(ln_dmod_kernel, dim3(64, chunks), dim3(256), 0, st, dy, dmod, B, hw, C, shift, wchunk);
+    WM_CHECK_LAUNCH();
+  }
+  return WM_OK;
+}

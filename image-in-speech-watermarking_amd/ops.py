@@ -1,0 +1,201 @@
+"""Tensor-level wrappers over the C ABI (include/wm_kernels.h).
+
+Each function takes contiguous fp32 CUDA tensors, launches on torch's current stream and returns
+nothing (outputs are passed in) — allocation policy belongs to the caller (the engine), so the same
+calls are hipGraph-capturable.  Nothing here has a PyTorch fallback.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import lib, check, ptr, WmGemm, WmConv, WmAttack
+
+MODE_FP32, MODE_BF16 = 0, 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise ValueError("libwm_hip ops need contiguous float32 tensors")
+
+
+def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=1, b_kc=1, a_op=0, b_op=0, bias=None, res=None, ldr=0,
+         rowscale=None, rows_per_scale=0, kscale=None, k_per_scale=0, gaux=None, ldg=0, b_ones=False, C2=None,
+         atomic_out=False, ksplit=0, mode=MODE_FP32):
+    g = WmGemm(ptr(A), ptr(B), ptr(Cout), M, N, K, lda, ldb, ldc, a_kc, b_kc, a_op, b_op, ptr(bias), ptr(res), ldr,
+               ptr(rowscale), rows_per_scale, ptr(kscale), k_per_scale, ptr(gaux), ldg, int(b_ones), ptr(C2),
+               int(atomic_out), ksplit, mode)
+    check(lib.wm_gemm(C.byref(g), _stream()), f"wm_gemm(M={M},N={N},K={K})")
+
+
+def linear_fwd(x, w, bias, out, mode, a_op=0, res=None, rowscale=None, rows_per_scale=0):
+    """out[M,N] = (op(x)[M,K] @ w[N,K]^T + bias) * rowscale + res"""
+    M, K = x.shape
+    N = w.shape[0]
+    gemm(x, w, out, M, N, K, K, K, N, 1, 1, a_op=a_op, bias=bias, res=res, ldr=N, rowscale=rowscale,
+         rows_per_scale=rows_per_scale, mode=mode)
+
+
+def linear_bwd_input(dy, w, dx, mode, rowscale=None, rows_per_scale=0, gaux=None):
+    """dx[M,K] = ((dy[M,N] @ w[N,K]) * rowscale) * gelu'(gaux)"""
+    M, N = dy.shape
+    K = w.shape[1]
+    gemm(dy, w, dx, M, K, N, N, K, K, 1, 0, rowscale=rowscale, rows_per_scale=rows_per_scale, gaux=gaux, ldg=K,
+         mode=mode)
+
+
+def linear_bwd_weight(dy, x, dw, db, mode, x_op=0, kscale=None, k_per_scale=0):
+    """dw[N,K] += (dy*kscale)^T[N,M] @ op(x)[M,K];  db[N] += column sums of dy*kscale"""
+    M, N = dy.shape
+    K = x.shape[1]
+    gemm(dy, x, dw, N, K, M, N, K, K, 0, 0, b_op=x_op, kscale=kscale, k_per_scale=k_per_scale,
+         b_ones=db is not None, C2=db, atomic_out=True, mode=mode)
+
+
+def layernorm_fwd(x, gamma, beta, mod, y, mean, rstd, hw, shift):
+    rows, Cc = x.shape
+    check(lib.wm_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(mod), ptr(y), ptr(mean), ptr(rstd), rows, Cc, hw,
+                               shift, _stream()), "wm_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dmod, hw, shift):
+    rows, Cc = x.shape
+    check(lib.wm_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dgamma),
+                               ptr(dbeta), ptr(dmod), rows, Cc, hw, shift, _stream()), "wm_layernorm_bwd")
+
+
+def winattn_fwd(qkv, table, out, B, hw, Cc, shift, mode):
+    check(lib.wm_winattn_fwd(ptr(qkv), ptr(table), ptr(out), B, hw, Cc, shift, mode, _stream()), "wm_winattn_fwd")
+
+
+def winattn_bwd(qkv, table, dout, dqkv, dtable, B, hw, Cc, shift, mode):
+    check(lib.wm_winattn_bwd(ptr(qkv), ptr(table), ptr(dout), ptr(dqkv), ptr(dtable), B, hw, Cc, shift, mode,
+                             _stream()), "wm_winattn_bwd")
+
+
+def dwconv_fwd(h1, w, b, h2, B, hw, Ch):
+    check(lib.wm_dwconv_fwd(ptr(h1), ptr(w), ptr(b), ptr(h2), B, hw, Ch, _stream()), "wm_dwconv_fwd")
+
+
+def dwconv_bwd(h1, dh2, w, dh1, dw, db, B, hw, Ch):
+    check(lib.wm_dwconv_bwd(ptr(h1), ptr(dh2), ptr(w), ptr(dh1), ptr(dw), ptr(db), B, hw, Ch, _stream()),
+          "wm_dwconv_bwd")
+
+
+def im2col(x, cols, B, hw, Cc):
+    check(lib.wm_im2col_4x4s2(ptr(x), ptr(cols), B, hw, Cc, _stream()), "wm_im2col_4x4s2")
+
+
+def col2im(dcols, dx, B, hw, Cc):
+    check(lib.wm_col2im_4x4s2(ptr(dcols), ptr(dx), B, hw, Cc, _stream()), "wm_col2im_4x4s2")
+
+
+def pixel_shuffle(y4, bias, dst, B, hw, Co, ldd, c0):
+    check(lib.wm_pixel_shuffle2(ptr(y4), ptr(bias), ptr(dst), B, hw, Co, ldd, c0, _stream()), "wm_pixel_shuffle2")
+
+
+def pixel_unshuffle(dsrc, dy4, B, hw, Co, lds, c0):
+    check(lib.wm_pixel_unshuffle2(ptr(dsrc), ptr(dy4), B, hw, Co, lds, c0, _stream()), "wm_pixel_unshuffle2")
+
+
+def copy_cols(src, lds, s0, dst, ldd, c0, rows, Cc, accumulate=False):
+    check(lib.wm_copy_cols(ptr(src), lds, s0, ptr(dst), ldd, c0, rows, Cc, int(accumulate), _stream()), "wm_copy_cols")
+
+
+def strided3(src, dst, n, si, so, atomic=False):
+    check(lib.wm_strided3(ptr(src), ptr(dst), n[0], n[1], n[2], si[0], si[1], si[2], so[0], so[1], so[2], int(atomic),
+                          _stream()), "wm_strided3")
+
+
+def msg_expand_fwd(feat, dst, B):
+    check(lib.wm_msg_expand_fwd(ptr(feat), ptr(dst), B, _stream()), "wm_msg_expand_fwd")
+
+
+def msg_expand_bwd(dcat, dfeat, B):
+    check(lib.wm_msg_expand_bwd(ptr(dcat), ptr(dfeat), B, _stream()), "wm_msg_expand_bwd")
+
+
+ACT = {"none": 0, "relu": 1, "leaky": 2, "sigmoid": 3}
+
+
+def conv_desc(B, Cin, H, W, Cout, k, stride=(1, 1), pad=(0, 0), in_nhwc=False, out_nhwc=False, act="none",
+              transposed=False):
+    kh, kw = k
+    if transposed:
+        OH, OW = H * stride[0], W * stride[1]
+    else:
+        OH = (H + 2 * pad[0] - kh) // stride[0] + 1
+        OW = (W + 2 * pad[1] - kw) // stride[1] + 1
+    return WmConv(B, Cin, H, W, Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], OH, OW, int(in_nhwc),
+                  int(out_nhwc), ACT[act], int(transposed))
+
+
+def conv_fwd(d, x, w, b, y):
+    check(lib.wm_conv_fwd(C.byref(d), ptr(x), ptr(w), ptr(b), ptr(y), _stream()), "wm_conv_fwd")
+
+
+def conv_bwd(d, x, w, y, dy, dx, dw, db, dx_accumulate=False):
+    check(lib.wm_conv_bwd(C.byref(d), ptr(x), ptr(w), ptr(y), ptr(dy), ptr(dx), int(dx_accumulate), ptr(dw), ptr(db),
+                          _stream()), "wm_conv_bwd")
+
+
+def maxpool_fwd(x, y, planes, H, W, kh, kw):
+    check(lib.wm_maxpool_fwd(ptr(x), ptr(y), planes, H, W, kh, kw, _stream()), "wm_maxpool_fwd")
+
+
+def maxpool_bwd(x, dy, dx, planes, H, W, kh, kw, accumulate=False):
+    check(lib.wm_maxpool_bwd(ptr(x), ptr(dy), ptr(dx), planes, H, W, kh, kw, int(accumulate), _stream()),
+          "wm_maxpool_bwd")
+
+
+def istft_fwd(spec, wave, B):
+    check(lib.wm_istft255_fwd(ptr(spec), ptr(wave), B, _stream()), "wm_istft255_fwd")
+
+
+def stft_fwd(wave, spec, B):
+    check(lib.wm_stft255_fwd(ptr(wave), ptr(spec), B, _stream()), "wm_stft255_fwd")
+
+
+def istft_bwd(dwave, dspec, B):
+    check(lib.wm_istft255_bwd(ptr(dwave), ptr(dspec), B, _stream()), "wm_istft255_bwd")
+
+
+def stft_bwd(dspec, dwave, B):
+    check(lib.wm_stft255_bwd(ptr(dspec), ptr(dwave), B, _stream()), "wm_stft255_bwd")
+
+
+def attack_fwd(desc, wave, out, sigma, B, L):
+    check(lib.wm_attack_fwd(C.byref(desc), ptr(wave), ptr(out), ptr(sigma), B, L, _stream()), "wm_attack_fwd")
+
+
+def attack_bwd(desc, wave, dout, sigma, dwave, B, L):
+    check(lib.wm_attack_bwd(C.byref(desc), ptr(wave), ptr(dout), ptr(sigma), ptr(dwave), B, L, _stream()),
+          "wm_attack_bwd")
+
+
+def loss_fwd_bwd(stft_new, x, noise, wm_pred, wm, msg, losses, d_stft_new, d_noise, d_wm_pred, d_wm, B, scratch):
+    check(lib.wm_loss_fwd_bwd(ptr(stft_new), ptr(x), ptr(noise), ptr(wm_pred), ptr(wm), ptr(msg), ptr(losses),
+                              ptr(d_stft_new), ptr(d_noise), ptr(d_wm_pred), ptr(d_wm), B, ptr(scratch), _stream()),
+          "wm_loss_fwd_bwd")
+
+
+def adamw(p, g, m, v, n, lr_t, b1, b2, eps, wd, step_t, gscale_t=None):
+    check(lib.wm_adamw(ptr(p), ptr(g), ptr(m), ptr(v), n, ptr(lr_t), b1, b2, eps, wd, ptr(step_t), ptr(gscale_t),
+                       _stream()), "wm_adamw")
+
+
+def step_inc(step_t):
+    check(lib.wm_step_inc(ptr(step_t), _stream()), "wm_step_inc")
+
+
+def droppath_scales(scales, rates, nslots, B, seed, step_t):
+    check(lib.wm_droppath_scales(ptr(scales), ptr(rates), nslots, B, seed, ptr(step_t), _stream()),
+          "wm_droppath_scales")
+
+
+def axpbyz(out, a, x, b, y, n):
+    check(lib.wm_axpbyz(ptr(out), a, ptr(x), b, ptr(y), n, _stream()), "wm_axpbyz")

@@ -1,0 +1,153 @@
+/* C ABI of libwm_hip.so — the MI355X (gfx950) kernels behind the watermark train step.
+ *
+ * The reference has no native/FFI surface: its hot path is PyTorch ATen calls inside
+ * uformerWM/model.py.  Each entry point below replaces the ATen op group named in its comment
+ * (file:line in /root/reference).  Conventions:
+ *   - every pointer is DEVICE memory (fp32 unless stated), owned by the caller, never retained;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it, no host sync,
+ *     no allocation (hipGraph-capturable);
+ *   - return 0 on success, WM_EINVAL (22) for a shape/alignment the kernel does not support,
+ *     1000+hipError_t for a launch failure.  Nothing is written on a non-zero return;
+ *   - `mode`: 0 = fp32 MFMA (exact fmaf-chain accumulation, "parity mode"),
+ *             1 = bf16 MFMA operands with fp32 accumulation ("fast mode");
+ *   - parameter-gradient outputs are ACCUMULATED with fp32 atomics into buffers the caller
+ *     zeroes once per step (the flat gradient arena).
+ */
+#ifndef WM_KERNELS_H
+#define WM_KERNELS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int wm_abi_version(void);
+
+/* ---- GEMM with fused prologue/epilogue -----------------------------------------------------
+ * C[m,n] = epi( sum_k opA(A(m,k)) * kscale[k/k_per_scale] * opB(B(n,k)) )
+ * epi(v) = ((v + bias[n]) * rowscale[m/rows_per_scale]) * gelu'(gaux[m,n]) + res[m,n]
+ * (each factor optional).  Replaces nn.Linear fwd/bwd + GELU + residual/DropPath adds of
+ * LinearProjection (model.py:460-471), WindowAttention.proj (:549), LeFF.linear1/2 (:700,711),
+ * Downsample/Upsample as im2col GEMMs (:763,789) and their autograd backward.
+ */
+typedef struct WmGemm {
+  const float* A; const float* B; float* C;
+  int32_t M, N, K;
+  int64_t lda, ldb, ldc;     /* lda: row stride if a_kc else k stride (elements); same for ldb */
+  int32_t a_kc, b_kc;        /* 1: operand is K-contiguous, 0: row-contiguous                   */
+  int32_t a_op, b_op;        /* 0 none, 1 GELU applied while staging the operand                */
+  const float* bias;         /* [N] or NULL                                                     */
+  const float* res; int64_t ldr;              /* residual [M,N] or NULL                        */
+  const float* rowscale; int32_t rows_per_scale; /* per-sample DropPath scale or NULL           */
+  const float* kscale; int32_t k_per_scale;   /* scale on A along K (weight-grad GEMMs) or NULL */
+  const float* gaux; int64_t ldg;             /* multiply by gelu'(gaux[m,n]) or NULL           */
+  int32_t b_ones;            /* B has a virtual row n==N of ones; that column is added to C2[m] */
+  float* C2;
+  int32_t atomic_out;        /* 1: atomicAdd into C (gradient accumulation, split-K)            */
+  int32_t ksplit;            /* >=1 number of K splits (needs atomic_out when >1); 0 = auto     */
+  int32_t mode;
+} WmGemm;
+int wm_gemm(const WmGemm* g, void* stream);
+
+/* ---- LayerNorm (+ window modulator) — model.py:982,1017 (norm1/norm2), :996-997 (modulator) ---- */
+int wm_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* modulator,
+                     float* y, float* mean, float* rstd, int64_t rows, int32_t C, int32_t hw,
+                     int32_t shift, void* stream);
+/* dx = dres + LN'(dy); dgamma/dbeta atomically accumulated; dmod[64,C] accumulated if not NULL */
+int wm_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                     const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                     float* dmod, int64_t rows, int32_t C, int32_t hw, int32_t shift, void* stream);
+
+/* ---- 8x8 window attention — model.py:523-551 with roll/partition/reverse (:987-1013) and the
+ * shift mask (:954-972) folded into the indexing.  qkv: [B*hw*hw, 3C] (q|k|v), heads of 32.    */
+int wm_winattn_fwd(const float* qkv, const float* bias_table, float* out, int32_t B, int32_t hw,
+                   int32_t C, int32_t shift, int32_t mode, void* stream);
+int wm_winattn_bwd(const float* qkv, const float* bias_table, const float* dout, float* dqkv,
+                   float* dbias_table, int32_t B, int32_t hw, int32_t C, int32_t shift,
+                   int32_t mode, void* stream);
+
+/* ---- LeFF depthwise 3x3 on token-major [B,hw,hw,Ch] — model.py:703-709.  Input is the
+ * PRE-GELU linear1 output; GELU is applied while staging.  Output is pre-GELU too.            */
+int wm_dwconv_fwd(const float* h1, const float* w, const float* b, float* h2, int32_t B, int32_t hw,
+                  int32_t Ch, void* stream);
+/* dh1 = gelu'(h1) * conv^T(dh2);  dw[Ch,9], db[Ch] accumulated */
+int wm_dwconv_bwd(const float* h1, const float* dh2, const float* w, float* dh1, float* dw, float* db,
+                  int32_t B, int32_t hw, int32_t Ch, void* stream);
+
+/* ---- data movement for Downsample (conv4x4 s2 p1, model.py:763) / Upsample (convT2x2 s2, :789) */
+int wm_im2col_4x4s2(const float* x, float* cols, int32_t B, int32_t hw, int32_t C, void* stream);
+int wm_col2im_4x4s2(const float* dcols, float* dx, int32_t B, int32_t hw, int32_t C, void* stream);
+/* y4: [B*hw*hw, 4*Co] columns ordered (di,dj,o)  <->  dst[B,(2hw)^2, ldd] channels [c0, c0+Co) */
+int wm_pixel_shuffle2(const float* y4, const float* bias /* [Co] or NULL */, float* dst, int32_t B, int32_t hw,
+                      int32_t Co, int64_t ldd, int32_t c0, void* stream);
+int wm_pixel_unshuffle2(const float* dsrc, float* dy4, int32_t B, int32_t hw, int32_t Co, int64_t lds,
+                        int32_t c0, void* stream);
+/* dst[r, c0:c0+C] = src[r, s0:s0+C] (skip concat, model.py:1225; and its backward slice)      */
+int wm_copy_cols(const float* src, int64_t lds, int32_t s0, float* dst, int64_t ldd, int32_t c0,
+                 int64_t rows, int32_t C, int32_t accumulate, void* stream);
+/* out[i0*so0+i1*so1+i2*so2] (=|atomic +=) in[i0*si0+i1*si1+i2*si2]: weight re-layouts for the conv GEMMs
+ * ([o][c][tap] <-> [o][tap][c], ConvTranspose [c][o][tap] <-> [tap][o][c]) and their gradient fold-back */
+int wm_strided3(const float* in, float* out, int32_t n0, int32_t n1, int32_t n2, int64_t si0, int64_t si1,
+                int64_t si2, int64_t so0, int64_t so1, int64_t so2, int32_t atomic, void* stream);
+
+/* ---- small direct convolutions (InputProj :814, OutputProj :846, stft_layer :2305,
+ * ConvAutoencoder :1700-1709, EncoderTransformerWM.conv2 :1566).  Layout flags: 0 = NCHW,
+ * 1 = token-major NHWC.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 sigmoid.                    */
+typedef struct WmConv {
+  int32_t B, Cin, H, W, Cout, KH, KW, SH, SW, PH, PW, OH, OW;
+  int32_t in_nhwc, out_nhwc, act, transposed;   /* transposed: ConvTranspose2d k == stride, no pad */
+} WmConv;
+int wm_conv_fwd(const WmConv* c, const float* x, const float* w, const float* b, float* y, void* stream);
+/* dy is the gradient w.r.t. the ACTIVATED output y; y is needed to undo the activation.
+ * dx (optional) is written or accumulated; dw/db (optional) are atomically accumulated.         */
+int wm_conv_bwd(const WmConv* c, const float* x, const float* w, const float* y, const float* dy,
+                float* dx, int32_t dx_accumulate, float* dw, float* db, void* stream);
+int wm_maxpool_fwd(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t kh, int32_t kw,
+                   void* stream);
+int wm_maxpool_bwd(const float* x, const float* dy, float* dx, int32_t planes, int32_t H, int32_t W,
+                   int32_t kh, int32_t kw, int32_t accumulate, void* stream);
+
+/* ---- in-graph STFT round trip — torch.istft / torch.stft with n_fft=255, hop 63, rectangular
+ * window, center/reflect (model.py:2458,2463).  spec: [B,2,128,128] (re|im planes), wave: [B,8002] */
+int wm_istft255_fwd(const float* spec, float* wave, int32_t B, void* stream);
+int wm_stft255_fwd(const float* wave, float* spec, int32_t B, void* stream);
+int wm_istft255_bwd(const float* dwave, float* dspec, int32_t B, void* stream);
+int wm_stft255_bwd(const float* dspec, float* dwave, int32_t B, void* stream);
+
+/* ---- waveform attacks (audio_attack.py:21-30,55-58,71-83,99-125; torch awgn model.py:15-41).
+ * One workgroup per waveform keeps the row in LDS through the whole chain.
+ * flags bit0 resample 16k->8k->16k, bit1 AWGN(snr_db), bit2 low-pass (FIR-expanded Butterworth-8
+ * filtfilt, taps `lp_h[lp_n]`), bit3 amplitude scale.  bwd applies the adjoint chain.            */
+typedef struct WmAttack {
+  int32_t flags; float snr_db; float amp; const float* lp_h; int32_t lp_n;
+  const float* rs_h; int32_t rs_n;          /* polyphase resampling prototype filter              */
+  uint64_t seed; const int64_t* step;       /* Philox stream = (seed, *step, row)                 */
+} WmAttack;
+int wm_attack_fwd(const WmAttack* a, const float* wave, float* out, float* sigma_out, int32_t B, int32_t L,
+                  void* stream);
+int wm_attack_bwd(const WmAttack* a, const float* wave, const float* dout, const float* sigma, float* dwave,
+                  int32_t B, int32_t L, void* stream);
+
+/* ---- loss of audio_uformer_stft.py:463-482 and its gradients ------------------------------- */
+/* losses[0..3] = l1..l4, [4] = total, [5] = ||noise||.  grads may alias nothing.               */
+int wm_loss_fwd_bwd(const float* stft_new, const float* x, const float* noise, const float* wm_pred,
+                    const float* wm, const float* msg, float* losses, float* d_stft_new, float* d_noise,
+                    float* d_wm_pred, float* d_wm, int32_t B, float* scratch, void* stream);
+
+/* ---- optimizer / utilities ----------------------------------------------------------------- */
+/* lr, step and grad_scale are read from DEVICE memory so a captured graph follows the scheduler */
+int wm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, float beta1, float beta2,
+             float eps, float wd, const int64_t* step, const float* grad_scale, void* stream);
+int wm_step_inc(int64_t* step, void* stream);
+int wm_droppath_scales(float* scales, const float* rates, int32_t nslots, int32_t B, uint64_t seed,
+                       const int64_t* step, void* stream);
+int wm_axpbyz(float* out, float a, const float* x, float b, const float* y /* or NULL */, int64_t n,
+              void* stream);                                     /* out = a*x + b*y */
+/* payload feature [B,4,64] tiled (1,16,8) into channels [0,512) of the bottleneck concat [B,64,1024]
+ * (model.py:2389,2411); bwd ACCUMULATES the folded gradient into dfeat [B,256]                   */
+int wm_msg_expand_fwd(const float* feat, float* dst, int32_t B, void* stream);
+int wm_msg_expand_bwd(const float* dcat, float* dfeat, int32_t B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,466 @@
+"""Per-kernel parity: every C-ABI entry point of libwm_hip.so against plain torch fp32 (CPU) references.
+
+Runs on the MI355X only (-m gpu).  fp32 "parity mode" kernels are held to 1e-4 relative (north_star),
+bf16 MFMA mode to bf16 rounding of the operands.
+"""
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import uformer_wm as O
+from oracle import attacks as OA
+from synth import synth_array
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wm():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return importlib.import_module("image-in-speech-watermarking_amd")
+
+
+def dev(t):
+    return t.contiguous().cuda()
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def assert_close(a, b, tol, what=""):
+    e = rel_err(a, b)
+    assert e <= tol, f"{what}: max rel err {e:.3e} > {tol:.1e}"
+
+
+TOL = {0: 1e-4, 1: 3e-2}
+
+
+# ---------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(300, 96, 64), (257, 32, 32), (130, 64, 128), (512, 200, 36), (64, 2048, 512)])
+def test_gemm_forward_epilogues(wm, mode, M, N, K):
+    ops = wm.ops
+    x, w = synth_array("gx", (M, K)), synth_array("gw", (N, K), 1.0 / math.sqrt(K))
+    bias, res = synth_array("gb", (N,)), synth_array("gr", (M, N))
+    rows_per = 10
+    rs = torch.rand((M + rows_per - 1) // rows_per) + 0.5
+    out = torch.empty(M, N, device="cuda")
+    ops.linear_fwd(dev(x), dev(w), dev(bias), out, mode, res=dev(res), rowscale=dev(rs), rows_per_scale=rows_per)
+    ref = (x @ w.t() + bias) * rs.repeat_interleave(rows_per)[:M, None] + res
+    assert_close(out, ref, TOL[mode], "linear_fwd")
+    # GELU applied to the A operand while staging
+    out2 = torch.empty(M, N, device="cuda")
+    ops.linear_fwd(dev(x), dev(w), dev(bias), out2, mode, a_op=1)
+    assert_close(out2, F.gelu(x) @ w.t() + bias, TOL[mode], "linear_fwd(gelu A)")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(320, 96, 64), (200, 32, 128), (192, 512, 40)])
+def test_gemm_backward_layouts(wm, mode, M, N, K):
+    """dX = dY W (B row-contiguous) and dW/db = dY^T [X|1] (both row-contiguous, atomics, split-K)."""
+    ops = wm.ops
+    dy, w, x = synth_array("bdy", (M, N)), synth_array("bw", (N, K), 1.0 / math.sqrt(N)), synth_array("bx", (M, K))
+    aux = synth_array("baux", (M, K))
+    rows_per = 64
+    rs = torch.rand((M + rows_per - 1) // rows_per) + 0.5
+    dx = torch.empty(M, K, device="cuda")
+    ops.linear_bwd_input(dev(dy), dev(w), dx, mode, rowscale=dev(rs), rows_per_scale=rows_per, gaux=dev(aux))
+    g = torch.autograd.functional.jvp(F.gelu, aux, torch.ones_like(aux))[1]
+    ref = (dy @ w) * rs.repeat_interleave(rows_per)[:M, None] * g
+    assert_close(dx, ref, TOL[mode], "linear_bwd_input")
+    for ks in (0, 1, 3):
+        dw = torch.zeros(N, K, device="cuda")
+        db = torch.zeros(N, device="cuda")
+        A, Bm = dev(dy), dev(x)
+        ops.gemm(A, Bm, dw, N, K, M, N, K, K, 0, 0, b_op=1, kscale=dev(rs), k_per_scale=rows_per, b_ones=True,
+                 C2=db, atomic_out=True, ksplit=ks, mode=mode)
+        dys = dy * rs.repeat_interleave(rows_per)[:M, None]
+        assert_close(dw, dys.t() @ F.gelu(x), TOL[mode] * (3 if mode else 1), f"dW ksplit={ks}")
+        assert_close(db, dys.sum(0), TOL[mode] * (3 if mode else 1), f"db ksplit={ks}")
+
+
+def test_gemm_rejects_bad_args(wm):
+    ops = wm.ops
+    a = torch.zeros(8, 6, device="cuda")
+    with pytest.raises(wm.WmKernelError):
+        ops.gemm(a, a, a, 8, 8, 6, 6, 6, 8)          # K not a multiple of 4
+
+
+# ---------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("C", [32, 64, 128, 256, 512])
+def test_layernorm_fwd_bwd(wm, C):
+    ops = wm.ops
+    B, hw, shift = 2, 16, 4
+    rows = B * hw * hw
+    x = synth_array("lnx", (rows, C)).requires_grad_()
+    gamma = (1 + 0.1 * synth_array("lng", (C,))).requires_grad_()
+    beta = (0.1 * synth_array("lnb", (C,))).requires_grad_()
+    use_mod = C >= 64
+    mod = synth_array("lnm", (64, C)).requires_grad_() if use_mod else None
+    y = F.layer_norm(x, (C,), gamma, beta)
+    if use_mod:
+        t = torch.roll(y.view(B, hw, hw, C), (-shift, -shift), (1, 2))
+        t = t.view(B, hw // 8, 8, hw // 8, 8, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 64, C) + mod
+        t = t.view(B, hw // 8, hw // 8, 8, 8, C).permute(0, 1, 3, 2, 4, 5).reshape(B, hw, hw, C)
+        y = torch.roll(t, (shift, shift), (1, 2)).reshape(rows, C)
+    dy, dres = synth_array("lndy", (rows, C)), synth_array("lndr", (rows, C))
+    y.backward(dy)
+    yo = torch.empty(rows, C, device="cuda")
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    xd, gd = dev(x.detach()), dev(gamma.detach())
+    ops.layernorm_fwd(xd, gd, dev(beta.detach()), dev(mod.detach()) if use_mod else None, yo, mean, rstd, hw, shift)
+    assert_close(yo, y.detach(), 1e-5, "ln fwd")
+    dx = torch.empty(rows, C, device="cuda")
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dm = torch.zeros(64, C, device="cuda") if use_mod else None
+    ops.layernorm_bwd(dev(dy), xd, gd, mean, rstd, dev(dres), dx, dg, db, dm, hw, shift)
+    assert_close(dx, x.grad + dres, 1e-4, "ln dx")
+    assert_close(dg, gamma.grad, 1e-4, "ln dgamma")
+    assert_close(db, beta.grad, 1e-4, "ln dbeta")
+    if use_mod:
+        assert_close(dm, mod.grad, 1e-4, "ln dmod")
+
+
+# ----------------------------------------------------------------------------- window attention
+def ref_winattn(qkv, table, B, hw, C, shift):
+    """Reference restated with torch ops on natural-order tokens (model.py:523-551, 954-1013)."""
+    heads = C // 32
+    t = qkv.view(B, hw, hw, 3 * C)
+    if shift:
+        t = torch.roll(t, (-shift, -shift), (1, 2))
+    t = t.view(B, hw // 8, 8, hw // 8, 8, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 64, 3, heads, 32)
+    q, k, v = (t[:, :, i].transpose(1, 2) for i in range(3))
+    s = (q * 32 ** -0.5) @ k.transpose(-1, -2)
+    s = s + table[O.rel_pos_index(8).reshape(-1)].view(64, 64, heads).permute(2, 0, 1)
+    if shift:
+        m = O.shift_attn_mask(hw, 8, shift)
+        nw = m.shape[0]
+        s = (s.view(B, nw, heads, 64, 64) + m[None, :, None]).view(-1, heads, 64, 64)
+    o = (s.softmax(-1) @ v).transpose(1, 2).reshape(-1, 64, C)
+    o = o.view(B, hw // 8, hw // 8, 8, 8, C).permute(0, 1, 3, 2, 4, 5).reshape(B, hw, hw, C)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    return o.reshape(B * hw * hw, C)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("hw,C,shift", [(16, 64, 0), (16, 64, 4), (8, 128, 0), (32, 32, 4)])
+def test_winattn_fwd_bwd(wm, mode, hw, C, shift):
+    ops = wm.ops
+    B, heads = 2, C // 32
+    qkv = synth_array("aqkv", (B * hw * hw, 3 * C)).requires_grad_()
+    table = (0.5 * synth_array("atab", (225, heads))).requires_grad_()
+    ref = ref_winattn(qkv, table, B, hw, C, shift)
+    do = synth_array("ado", ref.shape)
+    ref.backward(do)
+    out = torch.empty(B * hw * hw, C, device="cuda")
+    qd, td = dev(qkv.detach()), dev(table.detach())
+    ops.winattn_fwd(qd, td, out, B, hw, C, shift, mode)
+    assert_close(out, ref.detach(), TOL[mode], "attn fwd")
+    dqkv = torch.empty_like(qd)
+    dtab = torch.zeros_like(td)
+    ops.winattn_bwd(qd, td, dev(do), dqkv, dtab, B, hw, C, shift, mode)
+    assert_close(dqkv, qkv.grad, TOL[mode] * (2 if mode else 1), "attn dqkv")
+    assert_close(dtab, table.grad, TOL[mode] * (2 if mode else 1), "attn dtable")
+
+
+# ------------------------------------------------------------------------------------ dwconv
+@pytest.mark.parametrize("hw,Ch", [(16, 128), (8, 64), (32, 256)])
+def test_dwconv_fwd_bwd(wm, hw, Ch):
+    ops = wm.ops
+    B = 2
+    h1 = synth_array("dh1", (B, hw, hw, Ch)).requires_grad_()
+    w = (0.3 * synth_array("dw", (Ch, 1, 3, 3))).requires_grad_()
+    b = (0.1 * synth_array("db", (Ch,))).requires_grad_()
+    ref = F.conv2d(F.gelu(h1).permute(0, 3, 1, 2), w, b, padding=1, groups=Ch).permute(0, 2, 3, 1)
+    g = synth_array("dg", ref.shape)
+    ref.backward(g)
+    h2 = torch.empty(B, hw, hw, Ch, device="cuda")
+    hd, wd = dev(h1.detach()), dev(w.detach())
+    ops.dwconv_fwd(hd, wd, dev(b.detach()), h2, B, hw, Ch)
+    assert_close(h2, ref.detach(), 1e-5, "dwconv fwd")
+    dh1 = torch.empty_like(hd)
+    dwg, dbg = torch.zeros(Ch, 9, device="cuda"), torch.zeros(Ch, device="cuda")
+    ops.dwconv_bwd(hd, dev(g), wd, dh1, dwg, dbg, B, hw, Ch)
+    assert_close(dh1, h1.grad, 1e-4, "dwconv dh1")
+    assert_close(dwg, w.grad.reshape(Ch, 9), 1e-4, "dwconv dw")
+    assert_close(dbg, b.grad, 1e-4, "dwconv db")
+
+
+# --------------------------------------------------------------- down / up sampling data movement
+def test_im2col_col2im_match_conv4x4s2(wm):
+    ops = wm.ops
+    B, hw, C, Co = 2, 16, 32, 64
+    x = synth_array("ix", (B, hw, hw, C)).requires_grad_()
+    w = synth_array("iw", (Co, C, 4, 4), 0.05)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, None, stride=2, padding=1).permute(0, 2, 3, 1)
+    g = synth_array("ig", ref.shape)
+    ref.backward(g)
+    cols = torch.empty(B * (hw // 2) ** 2, 16 * C, device="cuda")
+    ops.im2col(dev(x.detach()), cols, B, hw, C)
+    w2 = w.permute(0, 2, 3, 1).reshape(Co, 16 * C)
+    assert_close(cols.cpu() @ w2.t(), ref.detach().reshape(-1, Co), 1e-5, "im2col")
+    dcols = dev(g.reshape(-1, Co) @ w2)
+    dx = torch.empty(B, hw, hw, C, device="cuda")
+    ops.col2im(dcols, dx, B, hw, C)
+    assert_close(dx, x.grad, 1e-5, "col2im")
+    # weight re-layout [o][c][tap] -> [o][tap][c] and back (atomic accumulate)
+    w2d = torch.empty(Co, 16, C, device="cuda")
+    ops.strided3(dev(w), w2d, (Co, 16, C), (C * 16, 1, 16), (16 * C, C, 1))
+    assert torch.equal(w2d.cpu().reshape(Co, 16 * C), w2)
+    back = torch.ones(Co, C, 16, device="cuda")
+    ops.strided3(w2d, back, (Co, 16, C), (16 * C, C, 1), (C * 16, 1, 16), atomic=True)
+    assert_close(back, w.reshape(Co, C, 16) + 1, 1e-6, "strided3 atomic")
+
+
+def test_pixel_shuffle_matches_convtranspose(wm):
+    ops = wm.ops
+    B, hw, Ci, Co = 2, 8, 64, 32
+    x = synth_array("px", (B, hw, hw, Ci))
+    w = synth_array("pw", (Ci, Co, 2, 2), 0.1)
+    bias = synth_array("pb", (Co,))
+    ref = F.conv_transpose2d(x.permute(0, 3, 1, 2), w, bias, stride=2).permute(0, 2, 3, 1)
+    wr = w.permute(2, 3, 1, 0).reshape(4 * Co, Ci)              # rows (di,dj,o)
+    y4 = dev(x.reshape(-1, Ci) @ wr.t())
+    dst = torch.full((B, 2 * hw, 2 * hw, 2 * Co), 7.0, device="cuda")
+    ops.pixel_shuffle(y4, dev(bias), dst, B, hw, Co, 2 * Co, Co)
+    assert_close(dst[..., Co:], ref, 1e-6, "pixel_shuffle")
+    assert torch.all(dst[..., :Co] == 7.0)
+    back = torch.empty(B * hw * hw, 4 * Co, device="cuda")
+    ops.pixel_unshuffle(dst, back, B, hw, Co, 2 * Co, Co)
+    assert_close(back, y4.cpu() + bias.repeat(4), 1e-6, "pixel_unshuffle")
+    src = dev(synth_array("cc", (50, 96)))
+    d2 = torch.zeros(50, 64, device="cuda")
+    ops.copy_cols(src, 96, 32, d2, 64, 16, 50, 32)
+    ops.copy_cols(src, 96, 32, d2, 64, 16, 50, 32, accumulate=True)
+    assert torch.equal(d2[:, 16:48].cpu(), 2 * src[:, 32:64].cpu()) and d2[:, :16].abs().sum() == 0
+
+
+def test_msg_expand(wm):
+    ops = wm.ops
+    B = 3
+    f = synth_array("mf", (B, 4, 64)).requires_grad_()
+    ref = f.repeat(1, 16, 8)
+    g = synth_array("mg", (B, 64, 1024))
+    ref.backward(g[..., :512])
+    dst = torch.zeros(B, 64, 1024, device="cuda")
+    ops.msg_expand_fwd(dev(f.detach()), dst, B)
+    assert torch.equal(dst[..., :512].cpu(), ref.detach())
+    df = torch.ones(B, 256, device="cuda")
+    ops.msg_expand_bwd(dev(g), df, B)
+    assert_close(df, f.grad.reshape(B, 256) + 1, 1e-5, "msg_expand_bwd")
+
+
+# ---------------------------------------------------------------------------------- small convs
+CONVS = [
+    # Cin, H, W, Cout, k, stride, pad, in_nhwc, out_nhwc, act, transposed
+    (2, 32, 32, 32, (3, 3), (1, 1), (1, 1), False, True, "leaky", False),      # InputProj
+    (64, 16, 16, 2, (3, 3), (1, 1), (1, 1), True, False, "none", False),       # OutputProj
+    (2, 24, 24, 4, (3, 3), (1, 1), (1, 1), False, False, "relu", False),       # stft_layer.0
+    (1, 32, 32, 16, (3, 3), (1, 1), (1, 1), False, False, "relu", False),      # ConvAutoencoder.conv1
+    (1, 64, 512, 1, (8, 8), (16, 8), (0, 0), False, False, "none", False),     # EncoderTransformerWM.conv2
+    (4, 8, 8, 16, (2, 2), (2, 2), (0, 0), False, False, "relu", True),         # t_conv1
+    (16, 16, 16, 1, (2, 2), (2, 2), (0, 0), False, False, "sigmoid", True),    # t_conv2
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_small_conv_fwd_bwd(wm, cfg):
+    ops = wm.ops
+    Cin, H, W, Cout, k, st, pad, inl, outl, act, tr = cfg
+    B = 2
+    x = synth_array("cx", (B, Cin, H, W)).requires_grad_()
+    wshape = (Cin, Cout) + k if tr else (Cout, Cin) + k
+    w = synth_array("cw", wshape, 1.0 / math.sqrt(Cin * k[0] * k[1])).requires_grad_()
+    b = (0.1 * synth_array("cb", (Cout,))).requires_grad_()
+    pre = F.conv_transpose2d(x, w, b, stride=st) if tr else F.conv2d(x, w, b, stride=st, padding=pad)
+    y = {"none": lambda t: t, "relu": F.relu, "leaky": lambda t: F.leaky_relu(t, 0.01), "sigmoid": torch.sigmoid}[act](pre)
+    g = synth_array("cg", y.shape)
+    y.backward(g)
+    d = ops.conv_desc(B, Cin, H, W, Cout, k, st, pad, inl, outl, act, tr)
+    xin = x.detach().permute(0, 2, 3, 1) if inl else x.detach()
+    yo = torch.empty((B, d.OH, d.OW, Cout) if outl else (B, Cout, d.OH, d.OW), device="cuda")
+    xd, wd = dev(xin), dev(w.detach())
+    ops.conv_fwd(d, xd, wd, dev(b.detach()), yo)
+    yref = y.detach().permute(0, 2, 3, 1) if outl else y.detach()
+    assert_close(yo, yref, 1e-5, "conv fwd")
+    gd = dev(g.permute(0, 2, 3, 1) if outl else g)
+    dx = torch.empty_like(xd)
+    dw, db = torch.zeros_like(wd), torch.zeros(Cout, device="cuda")
+    ops.conv_bwd(d, xd, wd, yo, gd, dx, dw, db)
+    assert_close(dx, x.grad.permute(0, 2, 3, 1) if inl else x.grad, 1e-4, "conv dx")
+    assert_close(dw, w.grad, 1e-4, "conv dw")
+    assert_close(db, b.grad, 1e-4, "conv db")
+
+
+@pytest.mark.parametrize("planes,H,W,kh,kw", [(8, 32, 32, 2, 2), (3, 64, 512, 16, 8)])
+def test_maxpool(wm, planes, H, W, kh, kw):
+    ops = wm.ops
+    x = synth_array("mpx", (1, planes, H, W)).requires_grad_()
+    y = F.max_pool2d(x, (kh, kw))
+    g = synth_array("mpg", y.shape)
+    y.backward(g)
+    yo = torch.empty(planes, H // kh, W // kw, device="cuda")
+    xd = dev(x.detach()[0])
+    ops.maxpool_fwd(xd, yo, planes, H, W, kh, kw)
+    assert torch.equal(yo.cpu(), y.detach()[0])
+    dx = torch.ones_like(xd)
+    ops.maxpool_bwd(xd, dev(g[0]), dx, planes, H, W, kh, kw, accumulate=True)
+    assert_close(dx, x.grad[0] + 1, 1e-6, "maxpool bwd")
+
+
+# ------------------------------------------------------------------------------- STFT round trip
+def test_stft_istft_fwd_bwd(wm, golden):
+    ops = wm.ops
+    B = 3
+    spec = synth_array("sspec", (B, 2, 128, 128)).requires_grad_()
+    wave_ref = O.istft255(spec)
+    gw = synth_array("sgw", (B, 8002))
+    wave_ref.backward(gw)
+    wave = torch.empty(B, 8002, device="cuda")
+    ops.istft_fwd(dev(spec.detach()), wave, B)
+    assert_close(wave, wave_ref.detach(), 1e-4, "istft fwd")
+    dspec = torch.empty(B, 2, 128, 128, device="cuda")
+    ops.istft_bwd(dev(gw), dspec, B)
+    assert_close(dspec, spec.grad, 1e-4, "istft bwd")
+    w = (0.2 * synth_array("sw", (B, 8002))).requires_grad_()
+    s_ref = O.stft255(w)
+    gs = synth_array("sgs", s_ref.shape)
+    s_ref.backward(gs)
+    s = torch.empty(B, 2, 128, 128, device="cuda")
+    ops.stft_fwd(dev(w.detach()), s, B)
+    assert_close(s, s_ref.detach(), 1e-4, "stft fwd")
+    dw = torch.empty(B, 8002, device="cuda")
+    ops.stft_bwd(dev(gs), dw, B)
+    assert_close(dw, w.grad, 1e-4, "stft bwd")
+    # golden produced by the reference's own torch.istft/torch.stft calls (model.py:2458,2463)
+    g2 = golden("g2_stft")
+    from synth import synth_tile
+    y = synth_tile(2, "g2_y", 1.0)
+    wv = torch.empty(2, 8002, device="cuda")
+    ops.istft_fwd(dev(y), wv, 2)
+    assert_close(wv, torch.from_numpy(g2["wave"]), 1e-4, "istft vs golden")
+    sp = torch.empty(2, 2, 128, 128, device="cuda")
+    ops.stft_fwd(dev(torch.from_numpy(g2["wave"])), sp, 2)
+    assert_close(sp, torch.from_numpy(g2["spec"]), 1e-4, "stft vs golden")
+
+
+# ---------------------------------------------------------------------------------- attacks
+def test_attacks_fwd_and_adjoint(wm):
+    att = wm.attacks
+    ops = wm.ops
+    B, L = 3, 8002
+    x = 0.1 * synth_array("atx", (B, L))
+    xd = dev(x)
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    # 1) noise extraction: AWGN only
+    cfg = att.AttackConfig(resample=False, snr_db=20.0, lowpass=False, amp=None, seed=7)
+    out, sigma = att.attack_forward(cfg, xd, step)
+    sig_ref = OA.awgn_sigma(x.numpy(), 20.0)
+    assert_close(sigma.cpu()[:, None], torch.from_numpy(sig_ref), 1e-4, "awgn sigma")
+    z = ((out.cpu() - x) / sigma.cpu()[:, None]).double().numpy()
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+    snr = 10 * np.log10((x.numpy() ** 2).mean(-1) / ((out.cpu().numpy() - x.numpy()) ** 2).mean(-1))
+    assert np.all(np.abs(snr - 20.0) < 0.3)
+    # 2) each deterministic stage and the full chain against the oracle (noise replayed through z)
+    for kw in (dict(resample=True), dict(lowpass=True), dict(amp=0.8), dict(resample=True, lowpass=True, amp=0.8)):
+        c = att.AttackConfig(resample=kw.get("resample", False), snr_db=None, lowpass=kw.get("lowpass", False),
+                             amp=kw.get("amp"), seed=7)
+        o, _ = att.attack_forward(c, xd, step)
+        ref = OA.attack_chain(x.numpy(), resample=c.resample, lowpass=c.lowpass, amp=c.amp)
+        assert_close(o, torch.from_numpy(ref), 1e-4, f"attack {kw}")
+    full = att.AttackConfig(resample=True, snr_db=20.0, lowpass=True, amp=0.8, seed=7)
+    o, sg = att.attack_forward(full, xd, step)
+    rs = OA.resampling(x.numpy())
+    o1, _ = att.attack_forward(att.AttackConfig(True, 20.0, False, None, 7), xd, step)
+    zz = (o1.cpu().double().numpy() - rs) / OA.awgn_sigma(rs, 20.0)
+    ref = OA.attack_chain(x.numpy(), resample=True, snr_db=20.0, z=zz, lowpass=True, amp=0.8)
+    assert_close(o, torch.from_numpy(ref), 2e-4, "full attack chain")
+    # 3) backward = exact adjoint of the linear stages: <A x, g> == <x, A^T g>
+    lin = att.AttackConfig(resample=True, snr_db=None, lowpass=True, amp=0.8, seed=7)
+    g = synth_array("atg", (B, L))
+    ax, _ = att.attack_forward(lin, xd, step)
+    atg = att.attack_backward(lin, xd, dev(g), None, step)
+    lhs = (ax.double().cpu() * g.double()).sum(-1)
+    rhs = (x.double() * atg.double().cpu()).sum(-1)
+    assert_close(lhs, rhs, 1e-4, "attack adjoint")
+    # 4) AWGN backward (sigma depends on the signal): directional derivative check in float64 on the oracle
+    c = att.AttackConfig(resample=False, snr_db=10.0, lowpass=False, amp=None, seed=7)
+    o, sg = att.attack_forward(c, xd, step)
+    zz = ((o.cpu() - x) / sg.cpu()[:, None]).double().numpy()
+    dgr = att.attack_backward(c, xd, dev(g), sg, step).cpu().double().numpy()
+    v = synth_array("atv", (B, L)).double().numpy()
+    eps = 1e-6
+    f = lambda xx: (OA.awgn(xx, 10.0, zz) * g.double().numpy()).sum()
+    fd = (f(x.double().numpy() + eps * v) - f(x.double().numpy() - eps * v)) / (2 * eps)
+    assert abs(fd - (dgr * v).sum()) <= 2e-3 * abs(fd) + 1e-6
+
+
+# ------------------------------------------------------------------------------- loss, AdamW, rng
+def test_loss_fwd_bwd(wm):
+    ops = wm.ops
+    B = 3
+    x = synth_array("lx", (B, 2, 128, 128))
+    ts = [synth_array("l" + n, s).requires_grad_() for n, s in
+          (("a", (B, 2, 128, 128)), ("n", (B, 2, 128, 128)), ("p", (B, 1, 32, 32)), ("w", (B, 1, 32, 32)))]
+    msg = (synth_array("lm", (B, 1, 32, 32)) > 0).float()
+    tot, terms = O.train_losses(ts, x, msg)
+    tot.backward()
+    losses = torch.zeros(8, device="cuda")
+    grads = [torch.empty_like(dev(t.detach())) for t in ts]
+    ops.loss_fwd_bwd(*[dev(t.detach()) for t in (ts[0],)], dev(x), dev(ts[1].detach()), dev(ts[2].detach()),
+                     dev(ts[3].detach()), dev(msg), losses, grads[0], grads[1], grads[2], grads[3], B,
+                     torch.zeros(8, device="cuda"))
+    assert_close(losses[:4], torch.stack(terms).detach(), 1e-5, "loss terms")
+    assert_close(losses[4], tot.detach(), 1e-5, "loss total")
+    for gk, t in zip(grads, ts):
+        assert_close(gk, t.grad, 1e-4, "loss grad")
+
+
+def test_adamw_matches_torch(wm):
+    ops = wm.ops
+    n = 10007
+    p0 = synth_array("op", (n,))
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    pd, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    lr = torch.tensor([2e-4], device="cuda")
+    for it in range(3):
+        g = synth_array(f"og{it}", (n,))
+        p.grad = g.clone()
+        opt.step()
+        ops.step_inc(step)
+        ops.adamw(pd, dev(g), m, v, n, lr, 0.9, 0.999, 1e-8, 0.02, step)
+    assert int(step.item()) == 3
+    assert_close(pd, p.detach(), 1e-6, "adamw")
+
+
+def test_droppath_scales(wm):
+    ops = wm.ops
+    nslots, B = 8, 4096
+    rates = torch.tensor([0.0, 0.1, 0.1, 0.5, 0.0, 0.25, 0.1, 0.1], device="cuda")
+    s = torch.empty(nslots, B, device="cuda")
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.droppath_scales(s, rates, nslots, B, 1234, step)
+    sc = s.cpu()
+    for i, r in enumerate(rates.cpu().tolist()):
+        vals = set(np.round(sc[i].unique().numpy(), 5).tolist())
+        if r == 0:
+            assert vals == {1.0}
+        else:
+            assert vals <= {0.0, round(1 / (1 - r), 5)}
+            assert abs((sc[i] > 0).float().mean().item() - (1 - r)) < 0.03
+    s2 = torch.empty_like(s)
+    ops.droppath_scales(s2, rates, nslots, B, 1234, step)
+    assert torch.equal(s, s2)                       # pure function of (seed, step)
+    ops.step_inc(step)
+    ops.droppath_scales(s2, rates, nslots, B, 1234, step)
+    assert not torch.equal(s, s2)
