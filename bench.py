@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Benchmark of the watermark train step on MI355X (contract: see the task brief / DESIGN.md "Measurement").
+
+  python bench.py --gpus N --steps K --warmup W [--batch B] [--attack none|full] [--mode bf16|fp32]
+
+Metric (BASELINE.json): audio-sec/s per train step (enc+attack+dec).  One step = zero_grad -> forward ->
+(attacks) -> 4-term loss -> backward -> (RCCL gradient all-reduce) -> AdamW on B synthetic (STFT tile, payload)
+pairs per GPU; a tile is 128 hops x 128 samples = 1.024 s of 16 kHz audio.  Prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+TILE_SECONDS = 1.024
+
+
+def synth_batch(batch, seed):
+    """chirp+noise waveforms -> data-prep STFT (256/128 rect, drop last bin) -> [B,2,128,128] tiles;
+    BinaryWM payload bits (audio_uformer_stft.py:231: randint(2,(32,32)), seed 42)."""
+    from synth import chirp_wave
+    tiles = []
+    for i in range(batch):
+        w = chirp_wave(16384 - 128, f"bench_{seed}_{i}")[None]
+        st = torch.stft(w, n_fft=256, hop_length=128, win_length=256, window=torch.ones(256), return_complex=True)
+        st = torch.view_as_real(st)[:, :-1]                       # [1,128,frames,2]  (audio_test.py:465-469)
+        st = torch.nn.functional.pad(st, (0, 0, 0, 128 - st.shape[2]))
+        tiles.append(st[0].permute(2, 0, 1))
+    g = torch.Generator().manual_seed(42 + seed)
+    msg = torch.randint(0, 2, (batch, 1, 32, 32), generator=g).float()
+    return torch.stack(tiles).contiguous(), msg
+
+
+def cpu_baseline(batch=4, steps=3):
+    """The oracle (CPU restatement, parity-pinned to the reference) timed on this box's host cores: same step
+    definition, fp32, train mode, AdamW.  Bounded sample so the default run stays within minutes."""
+    from oracle import uformer_wm as O
+    from synth import load_synth
+    torch.manual_seed(0)
+    net = load_synth(O.UformerAudio()).train()
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    x, msg = synth_batch(batch, 0)
+    gen = torch.Generator().manual_seed(1)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        out = net(x, msg, keeps=O.draw_keeps(net, batch, gen))
+        loss, _ = O.train_losses(out, x, msg)
+        loss.backward()
+        opt.step()
+        if it:
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": batch * TILE_SECONDS / med, "unit": "audio-sec/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{steps} timed steps (1 warm-up) of B={batch} tiles, fp32, train mode, AdamW; "
+                                      f"median {med:.3f} s/step", "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=24, help="tiles per GPU (reference hard-codes 24, audio_uformer_stft.py:50)")
+    ap.add_argument("--attack", default="none", choices=["none", "full"])
+    ap.add_argument("--mode", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the watermark hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    wm = importlib.import_module("image-in-speech-watermarking_amd")
+    from synth import load_synth
+
+    net = wm.UformerAudio(img_size=128, embed_dim=32, win_size=8, token_projection="linear", token_mlp="leff",
+                          depths=[1, 2, 8, 8, 2, 8, 8, 2, 1], modulator=True, dd_in=2, in_chans=2, audio_scale="0",
+                          compute_mode=a.mode)
+    load_synth(net)                                              # identical random-init weights on every rank
+    net = net.to(dev).train()
+    opt = wm.FusedAdamW(net, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    attack = wm.AttackConfig.full_stack() if a.attack == "full" else None
+    extract_from = "attacked" if attack is not None else "y"
+    step = wm.TrainStep(net, opt, a.batch, attack=attack, extract_from=extract_from, use_graph=not a.no_graph)
+    x, msg = synth_batch(a.batch, rank)
+    x, msg = x.to(dev), msg.to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(a.warmup, 2)):                            # >= 2: first call warms up + captures the graph
+        step.step(x, msg)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step.step(x, msg)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    losses = step.losses.cpu().tolist()
+
+    result = {
+        "metric": "audio-sec/s per train step (enc+attack+dec)", "value": world * a.batch * TILE_SECONDS * a.steps / dt,
+        "unit": "audio-sec/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
+        "config": {"workload": ("uformerWM Uformer-STFT, 1 s 16 kHz clips, 32x32 binary image payload, "
+                                + ("full audio_attack stack (resample+AWGN20dB+low-pass+amp0.8)" if attack else "Identity attack")
+                                + f", {a.mode}"),
+                   "tiles_per_gpu": a.batch, "global_tiles": world * a.batch, "audio_sec_per_tile": TILE_SECONDS,
+                   "parallelism": f"dp{world}", "graph": step.use_graph, "params_M": 68.71},
+        "loss_terms": losses[:5],
+    }
+    if rank == 0 and not a.no_kernel_timing:
+        prof = importlib.import_module("image-in-speech-watermarking_amd.profiling")
+        eager = wm.TrainStep(net, opt, a.batch, attack=attack, extract_from=extract_from, use_graph=False) \
+            if world == 1 else None
+        if eager is not None:
+            eager.step(x, msg)
+            torch.cuda.synchronize()
+            with prof.KernelTimer() as kt:
+                eager.step(x, msg)
+            rows = kt.summary()
+            total = sum(r["total_s"] for r in rows)
+            result["roofline"] = prof.roofline_of(rows[0])
+            result["roofline"]["share_of_step_kernel_time"] = rows[0]["total_s"] / total
+            stft_rows = [r for r in rows if r["kernel"] in ("istft_fwd", "stft_fwd", "istft_bwd", "stft_bwd", "attack_fwd", "attack_bwd")]
+            if stft_rows:
+                by, ts = sum(r["bytes"] for r in stft_rows), sum(r["total_s"] for r in stft_rows)
+                result["roofline_stft_path"] = {"bound": "hbm", "achieved": by / ts / 1e9, "peak": prof.HBM_PEAK_GBS,
+                                                "unit": "GB/s", "frac": by / ts / 1e9 / prof.HBM_PEAK_GBS, "traffic": None,
+                                                "alg_bytes_per_step": by, "time_us_per_step": ts * 1e6}
+            mf = [r for r in rows if r["kernel"].startswith("gemm_") or r["kernel"].startswith("winattn")]
+            fl, ts = sum(r["flops"] for r in mf), sum(r["total_s"] for r in mf)
+            result["mfma_path"] = {"achieved_TFLOPs": fl / ts / 1e12, "time_ms_per_step": ts * 1e3,
+                                   "alg_TFLOP_per_step": fl / 1e12}
+            result["kernel_breakdown"] = [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["total_s"] * 1e3, 3),
+                                           "avg_us": round(r["avg_us"], 1)} for r in rows[:12]]
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+        result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,3 +5,6 @@ surface.  Import with ``importlib.import_module("image-in-speech-watermarking_am
 """
 from ._lib import lib, WmKernelError, EXPORTS, LIB_PATH  # noqa: F401  (raises ImportError if the .so is missing)
 from . import ops, attacks  # noqa: F401
+from .model import UformerAudio, get_arch  # noqa: F401,E402
+from .train import FusedAdamW, TrainStep, GradSync  # noqa: F401,E402
+from .attacks import AttackConfig  # noqa: F401,E402

@@ -83,6 +83,9 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 __global__ void step_inc_kernel(int64_t* step) { *step += 1; }
+__global__ void zero_small_kernel(float* p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
 
 __global__ void droppath_kernel(float* __restrict__ scales, const float* __restrict__ rates, int nslots, int B,
                                 uint64_t seed, const int64_t* __restrict__ step) {
@@ -113,8 +116,9 @@ extern "C" int wm_loss_fwd_bwd(const float* stft_new, const float* x, const floa
   if (!stft_new || !x || !noise || !wm_pred || !wm || !msg || !losses || !scratch || B <= 0) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t n1 = (int64_t)B * 2 * 128 * 128, n2 = (int64_t)B * 32 * 32;
-  hipError_t e = hipMemsetAsync(scratch, 0, 4 * sizeof(float), st);
-  if (e != hipSuccess) return 1000 + (int)e;
+  // accumulators are cleared by a kernel, not hipMemsetAsync: a 16-byte memset NODE inside a captured hipGraph
+  // stopped clearing them from the second replay on (ROCm 7.2, observed on MI355X), a kernel node replays reliably
+  hipLaunchKernelGGL(zero_small_kernel, dim3(1), dim3(64), 0, st, scratch, 8);
   hipLaunchKernelGGL(sqdiff_kernel, dim3(grid_for(n1)), dim3(256), 0, st, stft_new, x, noise, n1, scratch + 0, scratch + 3);
   hipLaunchKernelGGL(sqdiff_kernel, dim3(grid_for(n2)), dim3(256), 0, st, wm_pred, msg, (const float*)nullptr, n2,
                      scratch + 1, (float*)nullptr);

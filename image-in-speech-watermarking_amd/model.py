@@ -154,7 +154,6 @@ class _ModelFn(torch.autograd.Function):
     def forward(ctx, anchor, net, x, message, opts):
         outs, saved = net._forward_impl(x, message, **opts)
         ctx.net, ctx.saved = net, saved
-        ctx.mark_non_differentiable()
         return tuple(outs)
 
     @staticmethod
@@ -208,29 +207,32 @@ class UformerAudio(nn.Module):
         seg_c = (_conv_specs("stft_layer.0.", 4, in_chans, 3, 3) + _conv_specs("stft_layer.2.", in_chans, 4, 3, 3) +
                  _trunk_specs(a, "decoder_wm.", True))
         self._specs = seg_a + seg_b + seg_c + unused
-        self._seg_sizes = [sum(math.prod(s[1]) for s in seg) for seg in (seg_a, seg_b, seg_c, unused)]
+        # every tensor starts on a 16-byte boundary (float4 loads); q|kv weights and biases stay adjacent because
+        # their sizes are multiples of 4 floats
+        self._offsets, self._seg_sizes, off = {}, [], 0
+        for seg in (seg_a, seg_b, seg_c, unused):
+            start = off
+            for name, shape, _ in seg:
+                self._offsets[name] = off
+                off += (math.prod(shape) + 3) // 4 * 4
+            self._seg_sizes.append(off - start)
         self._build_arena(torch.device("cpu"), init=True)
         self._anchor = None
         self._step_t = None
-        self._aux = {}
 
     # ---- parameter arena -------------------------------------------------------------------
-    def _build_arena(self, device, init=False, old=None):
+    def _build_arena(self, device, init=False, flat=None):
         total = sum(self._seg_sizes)
         pad = (-total) % 64
-        self._flat = torch.zeros(total + pad, device=device, dtype=torch.float32)
+        self._flat = torch.zeros(total + pad, device=device, dtype=torch.float32) if flat is None else flat
         self._flat_grad = torch.zeros(total + pad, device=device, dtype=torch.float32)
-        self._views, self._gviews, self._offsets = {}, {}, {}
-        off = 0
+        self._views, self._gviews = {}, {}
         for name, shape, kind in self._specs:
-            n = math.prod(shape)
+            n, off = math.prod(shape), self._offsets[name]
             v = self._flat[off:off + n].view(shape)
             if init:
                 _init_tensor(v, kind)
-            elif old is not None:
-                v.copy_(old[name])
-            self._views[name], self._gviews[name], self._offsets[name] = v, self._flat_grad[off:off + n].view(shape), off
-            off += n
+            self._views[name], self._gviews[name] = v, self._flat_grad[off:off + n].view(shape)
         for name, shape, kind in self._specs:
             node = self
             parts = name.split(".")
@@ -259,11 +261,9 @@ class UformerAudio(nn.Module):
         if probe.device != self._flat.device or probe.dtype != self._flat.dtype:
             if probe.dtype != torch.float32:
                 raise TypeError("the watermark model keeps fp32 master parameters; choose compute_mode='bf16' instead")
-            old = {k: v.clone() for k, v in self._views.items() if k in self._offsets}
-            self._build_arena(probe.device, old={k: fn(v) for k, v in old.items()})
-            self._anchor, self._step_t, self._aux = None, None, {}
-            return self
-        return super()._apply(fn, recurse) if False else self
+            self._build_arena(probe.device, flat=fn(self._flat).contiguous())
+            self._anchor, self._step_t = None, None
+        return self
 
     @property
     def optimized_numel(self):
@@ -369,7 +369,7 @@ class UformerAudio(nn.Module):
         dh1 = _E(dev, M, 4 * C)
         ops.dwconv_bwd(h1, dh2, P[pre + "mlp.dwconv.0.weight"], dh1, G[pre + "mlp.dwconv.0.weight"],
                        G[pre + "mlp.dwconv.0.bias"], B, hw, 4 * C)
-        dxn2 = dh2[:, :C] if False else _E(dev, M, C)
+        dxn2 = _E(dev, M, C)
         ops.linear_bwd_input(dh1, P[pre + "mlp.linear1.0.weight"], dxn2, mode)
         ops.linear_bwd_weight(dh1, xn2, G[pre + "mlp.linear1.0.weight"], G[pre + "mlp.linear1.0.bias"], mode)
         dx1 = _E(dev, M, C)
@@ -482,29 +482,24 @@ class UformerAudio(nn.Module):
             return z, tape
         return feats, tape
 
-    def _trunk_bwd(self, pre, tape, dfeats, dz):
-        """dfeats: list of 5 gradient tensors (or None) for the stage outputs; dz: grad of the conv2 map (extractor)."""
+    def _trunk_bwd(self, pre, tape, dfeats, dz=None):
+        """Backward through a trunk.  dfeats: gradients of the 5 stage outputs (encoder; entries may be None)
+        or None (extractor, where the only consumer is conv2 and ``dz`` is the gradient of its map).
+        Returns the gradient w.r.t. the trunk input (image for the extractor, tokens for the encoder)."""
         G, P = self._gviews, self._views
-        dy = None
+        dy = dfeats[4] if dfeats is not None else None
         for item in reversed(tape):
             kind = item[0]
             if kind == "conv2":
                 _, d2, x, z = item
                 dy = _E(x.device, *x.shape)
                 ops.conv_bwd(d2, x, P[pre + "conv2.weight"], z, dz, dy, G[pre + "conv2.weight"], G[pre + "conv2.bias"])
-                dfeats = [None, None, None, None, None]
-                stage = 4
-                pending = dy
-                dy = None
-                dfeats[4] = pending
             elif kind == "down":
                 _, sv, i = item
                 dy = self._down_bwd(sv, dy)
-                if dfeats[i] is not None:
+                if dfeats is not None and dfeats[i] is not None:
                     ops.axpbyz(dy, 1.0, dy, 1.0, dfeats[i], dy.numel())
             elif kind == "block":
-                if dy is None:
-                    dy = dfeats[4]
                 dy = self._block_bwd(item[1], dy)
             elif kind == "inproj":
                 _, d, img, y = item
@@ -634,7 +629,7 @@ class UformerAudio(nn.Module):
         S["B"], S["extract_from"], S["feats"] = B, extract_from, feats
         return (stft_new, noise, wm_pred, wm), S
 
-    def _backward_impl(self, S, d_stft_new, d_noise, d_wm_pred, d_wm):
+    def _backward_impl(self, S, d_stft_new, d_noise, d_wm_pred, d_wm, after_segment=None):
         P, G = self._views, self._gviews
         B = S["B"]
         dev = self._flat.device
@@ -653,6 +648,8 @@ class UformerAudio(nn.Module):
         ops.conv_bwd(c2, mid, P["stft_layer.2.weight"], stft_new, d_stft_new, dmid, G["stft_layer.2.weight"], G["stft_layer.2.bias"])
         dspec = _E(dev, B, 2, 128, 128)
         ops.conv_bwd(c1, spec, P["stft_layer.0.weight"], mid, dmid, dspec, G["stft_layer.0.weight"], G["stft_layer.0.bias"])
+        if after_segment is not None:
+            after_segment(0)                                        # extractor + stft_layer gradients are final
         if S["extract_from"] != "y":
             ops.axpbyz(dspec, 1.0, dspec, 1.0, d_src, dspec.numel())
         att, wave, sigma = S["stft"]
@@ -679,6 +676,8 @@ class UformerAudio(nn.Module):
                 _, sv, i = item
                 g, dskip = self._up_bwd(sv, g)
                 dfe[3 - i] = dskip
+        if after_segment is not None:
+            after_segment(1)                                        # decoder + output_proj gradients are final
         dcat = g                                                    # [B*64, 1024]
         dconv4 = _E(dev, B * 64, 512)
         ops.copy_cols(dcat, 1024, 512, dconv4, 512, 0, B * 64, 512)
@@ -689,22 +688,12 @@ class UformerAudio(nn.Module):
         ops.msg_expand_bwd(dcat, df0, B)
         dfe[4] = dconv4
         # --- encoder (segment A) ---
-        dtok0 = self._trunk_bwd_feats("encoder.", S["enc"], dfe)
+        dtok0 = self._trunk_bwd("encoder.", S["enc"], dfe)
         d_in, x, tok = S["inproj"]
         ops.conv_bwd(d_in, x, P["input_proj.proj.0.weight"], tok, dtok0, None, G["input_proj.proj.0.weight"], G["input_proj.proj.0.bias"])
         self._ae_encode_bwd(S["ae_enc"], df0, B)
-
-    def _trunk_bwd_feats(self, pre, tape, dfeats):
-        dy = dfeats[4]
-        for item in reversed(tape):
-            if item[0] == "down":
-                _, sv, i = item
-                dy = self._down_bwd(sv, dy)
-                if dfeats[i] is not None:
-                    ops.axpbyz(dy, 1.0, dy, 1.0, dfeats[i], dy.numel())
-            elif item[0] == "block":
-                dy = self._block_bwd(item[1], dy)
-        return dy
+        if after_segment is not None:
+            after_segment(2)
 
 
 def get_arch(opt):

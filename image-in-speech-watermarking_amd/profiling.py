@@ -1,0 +1,128 @@
+"""Live per-kernel timing with HIP events + the algorithmic work model used for roofline fractions.
+
+``KernelTimer`` wraps the tensor-level launch wrappers of ``ops`` so that every launch is bracketed by a
+start/stop event pair recorded on the stream the kernel runs on (torch's current stream).  It is used by
+``bench.py`` on an un-captured (eager) step: a hipGraph replay cannot host events between its nodes.
+Algorithmic bytes / flops per launch follow SURVEY.md 8(d) and DESIGN.md ("Kernels and their rooflines").
+"""
+import collections
+
+import torch
+
+from . import ops
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 achievable)
+MFMA_PEAK_TFLOPS = {0: 157.3, 1: 2500.0}   # dense fp32-input MFMA / dense bf16 MFMA (no sparsity)
+
+
+def _gemm_cost(a):
+    A, B, C, M, N, K = a[:6]
+    kw = a[-1]
+    flops = 2.0 * M * N * K
+    byts = 4.0 * (M * K + N * K + M * N)
+    if kw.get("res") is not None:
+        byts += 4.0 * M * N
+    if kw.get("gaux") is not None:
+        byts += 4.0 * M * N
+    return flops, byts
+
+
+def _attn_cost(B, hw, C, products):
+    wh = B * (hw // 8) ** 2 * (C // 32)
+    return products * 2.0 * 64 * 64 * 32 * wh
+
+
+COST = {
+    "gemm": lambda *a, **k: _gemm_cost(a + (k,)),
+    "winattn_fwd": lambda qkv, t, o, B, hw, C, sh, mode: (_attn_cost(B, hw, C, 2), 4.0 * B * hw * hw * 4 * C),
+    "winattn_bwd": lambda qkv, t, do, dq, dt, B, hw, C, sh, mode: (_attn_cost(B, hw, C, 6), 4.0 * B * hw * hw * 7 * C),
+    "dwconv_fwd": lambda h1, w, b, h2, B, hw, Ch: (18.0 * B * hw * hw * Ch, 8.0 * B * hw * hw * Ch),
+    "dwconv_bwd": lambda h1, d, w, dh, dw, db, B, hw, Ch: (54.0 * B * hw * hw * Ch, 16.0 * B * hw * hw * Ch),
+    "layernorm_fwd": lambda x, *a: (8.0 * x.numel(), 8.0 * x.numel()),
+    "layernorm_bwd": lambda dy, x, *a: (16.0 * x.numel(), 16.0 * x.numel()),
+    "im2col": lambda x, cols, *a: (0.0, 4.0 * (x.numel() + cols.numel())),
+    "col2im": lambda dc, dx, *a: (0.0, 4.0 * (dx.numel() + dc.numel())),
+    "pixel_shuffle": lambda y4, *a: (0.0, 8.0 * y4.numel()),
+    "pixel_unshuffle": lambda ds, dy4, *a: (0.0, 8.0 * dy4.numel()),
+    "copy_cols": lambda src, lds, s0, dst, ldd, c0, rows, C, accumulate=False: (0.0, 8.0 * rows * C),
+    "axpbyz": lambda out, a, x, b, y, n: (2.0 * n, 12.0 * n),
+    "istft_fwd": lambda s, w, B: (2.0 * 10.2e6 * B, B * (131072.0 + 32008.0)),
+    "stft_fwd": lambda w, s, B: (2.0 * 8.4e6 * B, B * (131072.0 + 32008.0)),
+    "istft_bwd": lambda w, s, B: (2.0 * 8.4e6 * B, B * (131072.0 + 32008.0)),
+    "stft_bwd": lambda s, w, B: (2.0 * 10.2e6 * B, B * (131072.0 + 32008.0)),
+    "attack_fwd": lambda d, w, o, s, B, L: (0.0, 8.0 * B * L),
+    "attack_bwd": lambda d, w, do, s, dw, B, L: (0.0, 12.0 * B * L),
+    "adamw": lambda p, g, m, v, n, *a: (12.0 * n, 28.0 * n),
+}
+
+
+class KernelTimer:
+    def __init__(self):
+        self.records = collections.defaultdict(list)      # key -> [(start_evt, stop_evt, flops, bytes)]
+        self._saved = {}
+
+    def _key(self, name, args, kwargs):
+        if name == "gemm":
+            M, N, K = args[3:6]
+            mode = kwargs.get("mode", 0)
+            n_eff = N + (1 if kwargs.get("b_ones") else 0)
+            tile = "256x32" if n_eff <= 32 else ("128x64" if n_eff <= 64 else "128x128")
+            return f"gemm_{'bf16' if mode else 'f32'}_{tile}", mode
+        if name.startswith("winattn"):
+            return f"{name}_{'bf16' if args[-1] else 'f32'}", args[-1]
+        return name, None
+
+    def __enter__(self):
+        for name in dir(ops):
+            fn = getattr(ops, name)
+            if not callable(fn) or name.startswith("_") or name in ("check", "ptr", "conv_desc", "linear_fwd",
+                                                                     "linear_bwd_input", "linear_bwd_weight"):
+                continue
+            if getattr(fn, "__module__", "") != ops.__name__:
+                continue
+            self._saved[name] = fn
+            setattr(ops, name, self._wrap(name, fn))
+        return self
+
+    def _wrap(self, name, fn):
+        def timed(*args, **kwargs):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn(*args, **kwargs)
+            e.record()
+            cost = COST.get(name)
+            fl, by = cost(*args, **kwargs) if cost else (0.0, 0.0)
+            key, mode = self._key(name, args, kwargs)
+            self.records[key].append((s, e, fl, by, mode))
+            return out
+        return timed
+
+    def __exit__(self, *exc):
+        for name, fn in self._saved.items():
+            setattr(ops, name, fn)
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        rows = []
+        for key, recs in self.records.items():
+            t = sum(s.elapsed_time(e) for s, e, *_ in recs) * 1e-3
+            rows.append(dict(kernel=key, launches=len(recs), total_s=t, avg_us=t / len(recs) * 1e6,
+                             flops=sum(r[2] for r in recs), bytes=sum(r[3] for r in recs), mode=recs[0][4]))
+        rows.sort(key=lambda r: -r["total_s"])
+        return rows
+
+
+def roofline_of(row):
+    """Roofline object (bench.py contract) for one summary row: MFMA-bound GEMMs / attention, HBM-bound otherwise."""
+    k = row["kernel"]
+    n = row["launches"]
+    if k.startswith("gemm_") or k.startswith("winattn"):
+        peak = MFMA_PEAK_TFLOPS[1 if row["mode"] else 0]
+        ach = row["flops"] / row["total_s"] / 1e12
+        return dict(kernel=k, bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None,
+                    launches=n, avg_launch_us=row["avg_us"], alg_flops_per_launch=row["flops"] / n,
+                    alg_bytes_per_launch=row["bytes"] / n)
+    ach = row["bytes"] / row["total_s"] / 1e9
+    return dict(kernel=k, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                traffic=None, launches=n, avg_launch_us=row["avg_us"], alg_bytes_per_launch=row["bytes"] / n)

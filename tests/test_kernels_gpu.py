@@ -452,11 +452,11 @@ def test_droppath_scales(wm):
     ops.droppath_scales(s, rates, nslots, B, 1234, step)
     sc = s.cpu()
     for i, r in enumerate(rates.cpu().tolist()):
-        vals = set(np.round(sc[i].unique().numpy(), 5).tolist())
+        vals = sc[i].unique().numpy()
         if r == 0:
-            assert vals == {1.0}
+            assert np.array_equal(vals, [1.0])
         else:
-            assert vals <= {0.0, round(1 / (1 - r), 5)}
+            assert all(np.isclose(v, 0.0) or np.isclose(v, 1 / (1 - r), rtol=1e-5) for v in vals)
             assert abs((sc[i] > 0).float().mean().item() - (1 - r)) < 0.03
     s2 = torch.empty_like(s)
     ops.droppath_scales(s2, rates, nslots, B, 1234, step)

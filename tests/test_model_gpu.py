@@ -1,0 +1,176 @@
+"""Whole-model parity of the HIP product against goldens produced by the reference (and the oracle).
+
+fp32 "parity mode": tensors within 1e-4 relative, decoded payload bits exact (north_star).
+bf16 mode: payload bits exact vs the fp32 oracle, deviation of tensors reported and bounded.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import uformer_wm as O
+from synth import load_synth, synth_bits, synth_tile
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def wm():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return importlib.import_module("image-in-speech-watermarking_amd")
+
+
+@pytest.fixture(scope="module")
+def net(wm):
+    m = wm.UformerAudio(img_size=128, embed_dim=32, win_size=8, token_projection="linear", token_mlp="leff",
+                        depths=[1, 2, 8, 8, 2, 8, 8, 2, 1], modulator=True, dd_in=2, in_chans=2, audio_scale="0")
+    load_synth(m)
+    return m.cuda()
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def test_state_dict_is_reference_compatible(net, golden):
+    ref = O.UformerAudio()
+    sd = net.state_dict()
+    assert set(sd) == set(ref.state_dict())
+    ref.load_state_dict({k: v.cpu() for k, v in sd.items()})      # shapes and names line up both ways
+    assert all(p.is_cuda for p in net.parameters())
+
+
+def test_g3_eval_forward_matches_reference_golden(net, golden):
+    g = golden("g3_model_eval")
+    net.eval()
+    net.compute_mode = "fp32"
+    x, msg = synth_tile(2, "g3_x").cuda(), synth_bits("g3_msg", (2, 1, 32, 32)).cuda()
+    with torch.no_grad():
+        out = net(x, msg)
+    for o, k in zip(out, ("stft_new", "noise", "wm_pred", "wm")):
+        assert rel(o, g[k]) <= 1e-4, (k, rel(o, g[k]))
+    tot, terms = O.train_losses([o.cpu() for o in out], x.cpu(), msg.cpu())
+    np.testing.assert_allclose(torch.stack(terms).numpy(), g["terms"], rtol=1e-4)
+    bits = out[3].round().clamp(0, 1).to(torch.uint8).cpu().numpy()
+    assert np.array_equal(bits, g["bits"])                         # decoded payload: bit exact
+    with torch.no_grad():
+        assert rel(net.wm_decode(x), g["wm_decode_x"]) <= 1e-4
+        y, wmp = net.feature_extract(x, msg)
+    assert rel(y[:, :, :8, :8], g["fe_y"]) <= 1e-4 and rel(wmp, g["fe_wm"]) <= 1e-4
+
+
+def _scales_from_golden_masks(net, masks):
+    """Golden masks are in DropPath call order and skip rate-0 blocks; the product wants [nslots, B] scales."""
+    net._ensure_runtime(torch.device("cuda"))
+    rates = net._rates_host
+    out = torch.ones(len(rates), masks.shape[1])
+    it = iter(masks)
+    for s, r in enumerate(rates):
+        if r > 0:
+            out[s] = next(it) / (1.0 - r)
+    assert next(it, None) is None
+    return out.cuda()
+
+
+def test_g4_train_step_gradients_match_reference_golden(net, golden, wm):
+    g = golden("g4_model_train")
+    load_synth(net)
+    net.train()
+    net.compute_mode = "fp32"
+    x, msg = synth_tile(2, "g4_x").cuda(), synth_bits("g4_msg", (2, 1, 32, 32)).cuda()
+    scales = _scales_from_golden_masks(net, T(g["masks"]))
+    net.zero_grad(set_to_none=True)
+    out = net(x, msg, keep_scales=scales)
+    tot, terms = O.train_losses(out, x, msg)                       # the trainer's own torch loss code
+    np.testing.assert_allclose(torch.stack(terms).detach().cpu().numpy(), g["terms"], rtol=1e-4)
+    assert rel(out[0][:, :, :16, :16], g["stft_new"]) <= 1e-4
+    tot.backward()
+    names = [str(n) for n in g["names"]]
+    gn = np.array([net.get_parameter(n).grad.norm().item() for n in names])
+    bad = [(n, a, b) for n, a, b in zip(names, gn, g["gnorm"]) if abs(a - b) > 2e-3 * b + 1e-6]
+    assert not bad, bad[:10]
+    for k in [k for k in g.files if k.startswith("g_")]:
+        name = k[2:].replace("__", ".")
+        assert rel(net.get_parameter(name).grad, g[k]) <= 2e-3, (name, rel(net.get_parameter(name).grad, g[k]))
+    # one fused AdamW step reproduces torch.optim.AdamW (audio_uformer_stft.py:252-255)
+    opt = wm.FusedAdamW(net, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    opt.step()
+    for k in [k for k in g.files if k.startswith("p_")]:
+        name = k[2:].replace("__", ".")
+        np.testing.assert_allclose(net.get_parameter(name).detach().cpu().numpy(), g[k], rtol=1e-4, atol=2e-6)
+    unused = net.get_parameter("encoder.input_proj.proj.0.weight")
+    assert torch.equal(unused.detach().cpu(), load_synth(O.UformerAudio()).encoder.input_proj.proj[0].weight.detach())
+
+
+def test_bf16_mode_bits_and_deviation(net, golden):
+    g = golden("g3_model_eval")
+    load_synth(net)
+    net.eval()
+    net.compute_mode = "bf16"
+    x, msg = synth_tile(2, "g3_x").cuda(), synth_bits("g3_msg", (2, 1, 32, 32)).cuda()
+    with torch.no_grad():
+        out = net(x, msg)
+    net.compute_mode = "fp32"
+    dev = {k: rel(o, g[k]) for o, k in zip(out, ("stft_new", "noise", "wm_pred", "wm"))}
+    print("bf16 deviation vs fp32 reference:", dev)
+    assert max(dev.values()) < 0.1
+    bits = out[3].round().clamp(0, 1).to(torch.uint8).cpu().numpy()
+    ber_vs_ref = np.mean(bits != g["bits"])
+    print("bf16 payload bit mismatches vs reference:", ber_vs_ref)
+    assert ber_vs_ref <= 0.01          # untrained synthetic net: sigmoid outputs within bf16 noise of 0.5 may flip
+
+
+def test_attacked_forward_backward_runs_and_matches_oracle(net, wm):
+    """Config 3 graph (attacks in the loop, extractor on the attacked spectrogram) against the oracle with the
+    attack chain expressed through the same linear operators (noise-free so it is deterministic)."""
+    from oracle import attacks as OA
+    load_synth(net)
+    net.eval()
+    cfg = wm.attacks.AttackConfig(resample=True, snr_db=None, lowpass=True, amp=0.8)
+    net.attack, net.extract_from = cfg, "attacked"
+    x, msg = synth_tile(2, "g3_x").cuda(), synth_bits("g3_msg", (2, 1, 32, 32)).cuda()
+    try:
+        out = net(x, msg)
+        loss, _ = O.train_losses(out, x, msg)
+        net.zero_grad(set_to_none=True)
+        loss.backward()
+        gsum = float(net._flat_grad.abs().sum())
+        assert np.isfinite(gsum) and gsum > 0
+        ref = load_synth(O.UformerAudio()).eval()
+
+        def attack(w):
+            return torch.from_numpy(OA.attack_chain(w.detach().numpy(), resample=True, lowpass=True, amp=0.8)).float()
+        with torch.no_grad():
+            rout = ref(x.cpu(), msg.cpu(), attack=attack, extract_from="attacked")
+        for o, r, k in zip(out, rout, ("stft_new", "noise", "wm_pred", "wm")):
+            assert rel(o, r) <= 2e-4, (k, rel(o, r))
+    finally:
+        net.attack, net.extract_from = None, "y"
+
+
+def test_train_step_graph_replay_equals_eager_and_learns(wm):
+    """TrainStep (captured hipGraph) == the same launches issued eagerly, and the loss goes down."""
+    def make():
+        m = wm.UformerAudio(modulator=True, drop_path_rate=0.0)
+        load_synth(m)
+        m = m.cuda().train()
+        return m, wm.FusedAdamW(m, lr=2e-4)
+    x, msg = synth_tile(2, "ts_x").cuda(), synth_bits("ts_msg", (2, 1, 32, 32)).cuda()
+    (m1, o1), (m2, o2) = make(), make()
+    s1 = wm.TrainStep(m1, o1, 2, use_graph=True)
+    s2 = wm.TrainStep(m2, o2, 2, use_graph=False)
+    l1, l2 = [], []
+    for _ in range(4):
+        s1.step(x, msg)
+        s2.step(x, msg)
+        l1.append(s1.losses.cpu().clone())
+        l2.append(s2.losses.cpu().clone())
+    for a, b in zip(l1, l2):
+        assert torch.allclose(a[:5], b[:5], rtol=2e-3, atol=1e-5), (a, b)     # atomics: order-dependent last bits
+    assert l1[-1][4] < l1[0][4]
+    assert rel(m1._flat[:m1.optimized_numel], m2._flat[:m2.optimized_numel].cpu()) < 1e-3
+    assert int(o1.step_t.item()) == 4
