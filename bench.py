@@ -46,6 +46,7 @@ def cpu_baseline(batch=4, steps=3):
     from oracle import uformer_wm as O
     from synth import load_synth
     torch.manual_seed(0)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))        # the 1-GPU box's CPU share; 128 threads oversubscribe
     net = load_synth(O.UformerAudio()).train()
     opt = torch.optim.AdamW(net.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
     x, msg = synth_batch(batch, 0)
@@ -77,6 +78,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--detail", action="store_true", help="per-shape GEMM timing table on stderr")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,6 +159,15 @@ def main():
             fl, ts = sum(r["flops"] for r in mf), sum(r["total_s"] for r in mf)
             result["mfma_path"] = {"achieved_TFLOPs": fl / ts / 1e12, "time_ms_per_step": ts * 1e3,
                                    "alg_TFLOP_per_step": fl / 1e12}
+            if a.detail:
+                eager.step(x, msg)
+                with prof.KernelTimer(detail=True) as kt2:
+                    eager.step(x, msg)
+                for r in kt2.summary()[:60]:
+                    fl = r["flops"] / max(r["total_s"], 1e-12) / 1e12
+                    bw = r["bytes"] / max(r["total_s"], 1e-12) / 1e9
+                    print(f"{r['kernel']:60s} n={r['launches']:4d} total={r['total_s']*1e3:8.3f} ms avg={r['avg_us']:9.1f} us "
+                          f"{fl:8.1f} TF/s {bw:8.1f} GB/s", file=sys.stderr)
             result["kernel_breakdown"] = [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["total_s"] * 1e3, 3),
                                            "avg_us": round(r["avg_us"], 1)} for r in rows[:12]]
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -19,12 +19,28 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
   } while (0)
 
 // ---- activations -------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_f(float x) {          // nn.GELU() (erf form)
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+// nn.GELU() is the erf form.  libm's erff costs several hundred (divergent) instructions per element and was the
+// single largest VALU cost of the step (GELU sits in GEMM prologues/epilogues and in both depthwise-conv kernels),
+// so erf is evaluated with Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, two orders below the 1e-4 parity bound):
+//   erf(z) = sign(z) * (1 - (a1 t + ... + a5 t^5) exp(-z^2)),  t = 1 / (1 + p |z|)
+// With z = x/sqrt(2) the exponential exp(-x^2/2) is shared by gelu'(x) = Phi(x) + x phi(x).
+__device__ __forceinline__ float phi_tail_f(float x, float e) {          // 0.5 * erfc(|x|/sqrt2), e = exp(-x^2/2)
+  const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  return 0.5f * p * t * e;
 }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  return cdf + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+__device__ __forceinline__ float gelu_f(float x) {          // x * Phi(x)
+  const float e = __expf(-0.5f * x * x);
+  const float q = phi_tail_f(x, e);                          // Phi(-|x|)
+  return x * (x >= 0.f ? 1.0f - q : q);
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {     // Phi(x) + x * phi(x)
+  const float e = __expf(-0.5f * x * x);
+  const float q = phi_tail_f(x, e);
+  return (x >= 0.f ? 1.0f - q : q) + x * 0.39894228040143268f * e;
 }
 
 // ---- LDS element types: float (exact "parity" mode) or bf16 (fast mode) --------------------

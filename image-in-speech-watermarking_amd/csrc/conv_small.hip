@@ -54,7 +54,25 @@ __global__ void conv_fwd_kernel(const WmConv c, const float* __restrict__ x, con
     int b, co, oy, ox;
     out_decode(c, idx, b, co, oy, ox);
     float acc = bias ? bias[co] : 0.f;
-    if (!c.transposed) {
+    if (!c.transposed && c.in_nhwc && (c.Cin & 3) == 0) {
+      // channel-contiguous input (OutputProj): 16-B loads along Cin; the weight index is wave-uniform for NCHW output
+      for (int ky = 0; ky < c.KH; ++ky) {
+        const int iy = oy * c.SH - c.PH + ky;
+        if (iy < 0 || iy >= c.H) continue;
+        for (int kx = 0; kx < c.KW; ++kx) {
+          const int ix = ox * c.SW - c.PW + kx;
+          if (ix < 0 || ix >= c.W) continue;
+          const float4* xp = reinterpret_cast<const float4*>(x + (((int64_t)b * c.H + iy) * c.W + ix) * c.Cin);
+          const float* wp = w + ((int64_t)co * c.Cin * c.KH + ky) * c.KW + kx;
+          const int ws = c.KH * c.KW;
+          for (int c4 = 0; c4 < c.Cin / 4; ++c4) {
+            const float4 v = xp[c4];
+            acc += v.x * wp[(4 * c4 + 0) * ws] + v.y * wp[(4 * c4 + 1) * ws] + v.z * wp[(4 * c4 + 2) * ws] +
+                   v.w * wp[(4 * c4 + 3) * ws];
+          }
+        }
+      }
+    } else if (!c.transposed) {
       for (int ci = 0; ci < c.Cin; ++ci)
         for (int ky = 0; ky < c.KH; ++ky) {
           const int iy = oy * c.SH - c.PH + ky;
@@ -81,7 +99,29 @@ __global__ void conv_dx_kernel(const WmConv c, const float* __restrict__ w, cons
     int b, ci, iy, ix;
     in_decode(c, idx, b, ci, iy, ix);
     float acc = 0.f;
-    if (!c.transposed) {
+    if (!c.transposed && c.out_nhwc && (c.Cout & 3) == 0 && c.SH == 1 && c.SW == 1) {
+      // channel-contiguous output gradient (InputProj): 16-B loads of dy and y along Cout
+      for (int ky = 0; ky < c.KH; ++ky) {
+        const int oy = iy + c.PH - ky;
+        if (oy < 0 || oy >= c.OH) continue;
+        for (int kx = 0; kx < c.KW; ++kx) {
+          const int ox = ix + c.PW - kx;
+          if (ox < 0 || ox >= c.OW) continue;
+          const int64_t o = (((int64_t)b * c.OH + oy) * c.OW + ox) * c.Cout;
+          const float4* gp = reinterpret_cast<const float4*>(dy + o);
+          const float4* yp = reinterpret_cast<const float4*>(y + o);
+          const float* wp = w + ((int64_t)ci * c.KH + ky) * c.KW + kx;
+          const int ws = c.Cin * c.KH * c.KW;
+          for (int c4 = 0; c4 < c.Cout / 4; ++c4) {
+            const float4 gv = gp[c4], yv = yp[c4];
+            acc += gv.x * act_grad_from_out(yv.x, c.act) * wp[(4 * c4 + 0) * ws] +
+                   gv.y * act_grad_from_out(yv.y, c.act) * wp[(4 * c4 + 1) * ws] +
+                   gv.z * act_grad_from_out(yv.z, c.act) * wp[(4 * c4 + 2) * ws] +
+                   gv.w * act_grad_from_out(yv.w, c.act) * wp[(4 * c4 + 3) * ws];
+          }
+        }
+      }
+    } else if (!c.transposed) {
       for (int ky = 0; ky < c.KH; ++ky) {
         const int ty = iy + c.PH - ky;
         if (ty < 0 || ty % c.SH) continue;
@@ -159,6 +199,74 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const WmConv c, const floa
   }
 }
 
+
+// Weight/bias gradient of a 3x3, stride 1, pad 1 convolution (InputProj, OutputProj, stft_layer, ConvAutoencoder):
+// one workgroup walks 8x8-pixel tiles, staging the input tile + halo and the activation-corrected output gradient
+// in LDS; every thread owns up to MAXW weight elements (and the biases) and accumulates over the tile's 64 pixels.
+// One atomic per weight per workgroup instead of one workgroup per weight re-reading the whole tensor.
+constexpr int DW_MAXW = 5;                 // 256 threads x 5 >= 1152 + 64 (largest: OutputProj 2x64x3x3 + bias)
+__global__ __launch_bounds__(256) void conv3x3_dw_kernel(const WmConv c, const float* __restrict__ x,
+                                                         const float* __restrict__ y, const float* __restrict__ dy,
+                                                         float* __restrict__ dw, float* __restrict__ db,
+                                                         int tiles_per_block) {
+  extern __shared__ float sm[];
+  float* xin = sm;                          // [100][Cin]
+  float* dpre = sm + 100 * c.Cin;           // [64][Cout]
+  const int tid = threadIdx.x;
+  const int nW = c.Cout * c.Cin * 9, nAll = nW + (db ? c.Cout : 0);
+  const int tw = c.W / 8, th = c.H / 8, ntiles = c.B * th * tw;
+  int wco[DW_MAXW], wxi[DW_MAXW];           // per owned element: output channel, LDS offset of its input tap
+  float acc[DW_MAXW];
+#pragma unroll
+  for (int q = 0; q < DW_MAXW; ++q) {
+    const int e = tid + 256 * q;
+    acc[q] = 0.f;
+    wco[q] = -1; wxi[q] = 0;
+    if (e < nW) {
+      const int kx = e % 3, ky = (e / 3) % 3, ci = (e / 9) % c.Cin;
+      wco[q] = e / (9 * c.Cin);
+      wxi[q] = (ky * 10 + kx) * c.Cin + ci;
+    } else if (e < nAll) {
+      wco[q] = e - nW;
+      wxi[q] = -1;                          // bias: sum of dpre only
+    }
+  }
+  for (int t = blockIdx.x * tiles_per_block; t < min(ntiles, (int)(blockIdx.x + 1) * tiles_per_block); ++t) {
+    const int b = t / (th * tw), tr = t - b * th * tw, ty = tr / tw, tx = tr - ty * tw;
+    __syncthreads();
+    for (int i = tid; i < 100 * c.Cin; i += 256) {
+      int pix, ci;
+      if (c.in_nhwc) { ci = i % c.Cin; pix = i / c.Cin; } else { pix = i % 100; ci = i / 100; }
+      const int gy = ty * 8 + pix / 10 - 1, gx = tx * 8 + pix % 10 - 1;
+      xin[pix * c.Cin + ci] = (gy >= 0 && gy < c.H && gx >= 0 && gx < c.W) ? x[in_off(c, b, ci, gy, gx)] : 0.f;
+    }
+    for (int i = tid; i < 64 * c.Cout; i += 256) {
+      int p, co;
+      if (c.out_nhwc) { co = i % c.Cout; p = i / c.Cout; } else { p = i % 64; co = i / 64; }
+      const int64_t o = out_off(c, b, co, ty * 8 + (p >> 3), tx * 8 + (p & 7));
+      dpre[p * c.Cout + co] = dy[o] * act_grad_from_out(y[o], c.act);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < DW_MAXW; ++q) {
+      if (wco[q] < 0) continue;
+      float a = 0.f;
+      if (wxi[q] >= 0) {
+        for (int p = 0; p < 64; ++p) a += dpre[p * c.Cout + wco[q]] * xin[((p >> 3) * 10 + (p & 7)) * c.Cin + wxi[q]];
+      } else {
+        for (int p = 0; p < 64; ++p) a += dpre[p * c.Cout + wco[q]];
+      }
+      acc[q] += a;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < DW_MAXW; ++q) {
+    const int e = tid + 256 * q;
+    if (wco[q] < 0) continue;
+    if (e < nW) atomicAdd(dw + e, acc[q]); else atomicAdd(db + (e - nW), acc[q]);
+  }
+}
+
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int kh, int kw,
                                    int64_t total) {
   const int oh = H / kh, ow = W / kw;
@@ -231,7 +339,16 @@ extern "C" int wm_conv_bwd(const WmConv* c, const float* x, const float* w, cons
     hipLaunchKernelGGL(conv_dx_kernel, dim3(grid_for(total)), dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate, total);
     WM_CHECK_LAUNCH();
   }
-  if (dw) {
+  const bool tiled = dw && !c->transposed && c->KH == 3 && c->KW == 3 && c->SH == 1 && c->SW == 1 && c->PH == 1 &&
+                     c->PW == 1 && (c->H % 8) == 0 && (c->W % 8) == 0 &&
+                     c->Cout * c->Cin * 9 + c->Cout <= 256 * DW_MAXW && (100 * c->Cin + 64 * c->Cout) * 4 <= 60000;
+  if (tiled) {
+    const int ntiles = c->B * (c->H / 8) * (c->W / 8);
+    const int tpb = ntiles >= 4096 ? 8 : (ntiles >= 512 ? 2 : 1);
+    const size_t smem = sizeof(float) * (100 * c->Cin + 64 * c->Cout);
+    hipLaunchKernelGGL(conv3x3_dw_kernel, dim3((ntiles + tpb - 1) / tpb), dim3(256), smem, st, *c, x, y, dy, dw, db, tpb);
+    WM_CHECK_LAUNCH();
+  } else if (dw) {
     const int nW = c->Cout * c->Cin * c->KH * c->KW;
     hipLaunchKernelGGL(conv_dw_kernel, dim3(nW + (db ? c->Cout : 0)), dim3(256), 0, st, *c, x, y, dy, dw, db);
     WM_CHECK_LAUNCH();

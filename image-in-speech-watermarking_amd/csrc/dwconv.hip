@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
 }
 
 // dh1 = gelu'(h1) * sum_k w[k] * dh2[p - off_k];  dw[c][k] += sum_p dh2[p] * gelu(h1)[p + off_k]; db += sum_p dh2
-__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict__ h1, const float* __restrict__ dh2,
+__global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(const float* __restrict__ h1, const float* __restrict__ dh2,
                                                          const float* __restrict__ w, float* __restrict__ dh1,
                                                          float* __restrict__ dw, float* __restrict__ db, int B,
                                                          int hw, int Ch) {
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
     load_halo_tile(ta, h1, b, ty, tx, hw, Ch, cbase, true, tid);
     load_halo_tile(tg, dh2, b, ty, tx, hw, Ch, cbase, false, tid);
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {                          // one pixel at a time: 76 live accumulators/weights already
       const int pix = pg * 4 + q, py = pix >> 3, px = pix & 7;
       const float4 gc = *reinterpret_cast<const float4*>(tg + ((py + 1) * HP + px + 1) * TC + 4 * c4);
       float o[4] = {0.f, 0.f, 0.f, 0.f};

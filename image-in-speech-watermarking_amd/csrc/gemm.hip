@@ -6,50 +6,56 @@
 //   forward  Y  = X  W^T        A kc, B kc
 //   dX          = dY W          A kc, B row-contiguous
 //   dW (+db)    = dY^T [X | 1]  A row-contiguous, B row-contiguous (+ virtual ones row)
-// One workgroup = 256 threads = 4 waves; each wave owns TM x TN tiles of 32x32 (MFMA 32x32xK,
-// f32 accumulators).  Next K-tile's global loads are issued before the current tile's MFMAs.
+// One workgroup = 256 threads = 4 waves; each wave owns TM x TN tiles of 32x32 (MFMA 32x32xK, f32
+// accumulators).  LDS is double-buffered: the next K-tile's global loads are issued before the current
+// tile's MFMAs and written to the other buffer after them, one barrier per K-tile.  The tile shape is
+// picked per launch so that the grid covers the 256 CUs (small-M stages use 64x64 tiles).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/wm_kernels.h"
 
 namespace {
 
-constexpr int BK = 32;
-
-template <int R> struct TileRegs {
-  static constexpr int N = (R >= 128) ? R / 32 : 4;
+template <int R, int BK> struct TileRegs {
+  static constexpr int KC_N = R * BK / 4 / 256 > 0 ? R * BK / 4 / 256 : 1;                  // float4 per thread, K-contiguous
+  static constexpr int TPK = R / 4;                                                        // threads per 4-wide k block
+  static constexpr int KBP = 256 / TPK;                                                    // k blocks per pass
+  static constexpr int PASSES = (BK / 4 + KBP - 1) / KBP;
+  static constexpr int N = KC_N > 4 * PASSES ? KC_N : 4 * PASSES;
   float4 v[N];
 };
 
-template <int R>
-__device__ __forceinline__ void load_tile(TileRegs<R>& t, const float* __restrict__ p, bool kc, int64_t ld,
+template <int R, int BK>
+__device__ __forceinline__ void load_tile(TileRegs<R, BK>& t, const float* __restrict__ p, bool kc, int64_t ld,
                                           int row0, int rmax, int k0, int kend, bool ones, int tid) {
+  using TR = TileRegs<R, BK>;
   if (kc) {
-    const int r = tid >> 3, kq = tid & 7;
+    constexpr int TPR = BK / 4;                         // threads per row
+    constexpr int RPP = 256 / TPR;                      // rows per pass
+    const int r = tid / TPR, kq = tid % TPR;
     const int k = k0 + 4 * kq;
 #pragma unroll
-    for (int q = 0; q < R / 32; ++q) {
-      const int row = row0 + r + 32 * q;
+    for (int q = 0; q < TR::KC_N; ++q) {
+      const int rl = r + RPP * q;
+      const int row = row0 + rl;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < kend) {
+      if (rl < R && k < kend) {
         if (row < rmax) v = *reinterpret_cast<const float4*>(p + (int64_t)row * ld + k);
         else if (ones && row == rmax) v = make_float4(1.f, 1.f, 1.f, 1.f);
       }
       t.v[q] = v;
     }
   } else {
-    constexpr int TPK = R / 4;                                   // threads per 4-wide k block
-    constexpr int KBP = 256 / TPK;                               // k blocks per pass
-    constexpr int PASSES = (8 + KBP - 1) / KBP;
-    const int kb = tid / TPK, r4 = tid % TPK;
+    const int kb = tid / TR::TPK, r4 = tid % TR::TPK;
     const int row = row0 + 4 * r4;
 #pragma unroll
-    for (int q = 0; q < PASSES; ++q) {
-      const int kbb = kb + q * KBP;
+    for (int q = 0; q < TR::PASSES; ++q) {
+      const int kbb = kb + q * TR::KBP;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = k0 + 4 * kbb + i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kbb < 8 && k < kend) {
+        if (kbb < BK / 4 && k < kend) {
           const float* src = p + (int64_t)k * ld + row;
           if (row + 3 < rmax) {
             v = *reinterpret_cast<const float4*>(src);
@@ -71,33 +77,35 @@ __device__ __forceinline__ void load_tile(TileRegs<R>& t, const float* __restric
 
 __device__ __forceinline__ float apply_op(float x, int op) { return op == 1 ? gelu_f(x) : x; }
 
-template <int R, typename LT>
-__device__ __forceinline__ void store_tile(const TileRegs<R>& t, LT* __restrict__ s, bool kc, int op,
+template <int R, int BK, typename LT>
+__device__ __forceinline__ void store_tile(const TileRegs<R, BK>& t, LT* __restrict__ s, bool kc, int op,
                                            const float* __restrict__ kscale, int kps, int row0, int rmax,
                                            int k0, int tid) {
+  using TR = TileRegs<R, BK>;
   constexpr int LD = BK + LdsT<LT>::PAD;
   if (kc) {
-    const int r = tid >> 3, kq = tid & 7;
+    constexpr int TPR = BK / 4;
+    constexpr int RPP = 256 / TPR;
+    const int r = tid / TPR, kq = tid % TPR;
     float sc = 1.f;
     if (kscale) sc = kscale[(k0 + 4 * kq) / kps];
 #pragma unroll
-    for (int q = 0; q < R / 32; ++q) {
-      const int rl = r + 32 * q;
-      float4 v = t.v[q];
-      if (op && row0 + rl < rmax) {
-        v.x = apply_op(v.x, op); v.y = apply_op(v.y, op); v.z = apply_op(v.z, op); v.w = apply_op(v.w, op);
+    for (int q = 0; q < TR::KC_N; ++q) {
+      const int rl = r + RPP * q;
+      if (rl < R) {
+        float4 v = t.v[q];
+        if (op && row0 + rl < rmax) {
+          v.x = apply_op(v.x, op); v.y = apply_op(v.y, op); v.z = apply_op(v.z, op); v.w = apply_op(v.w, op);
+        }
+        LdsT<LT>::store4(s + rl * LD + 4 * kq, v.x * sc, v.y * sc, v.z * sc, v.w * sc);
       }
-      LdsT<LT>::store4(s + rl * LD + 4 * kq, v.x * sc, v.y * sc, v.z * sc, v.w * sc);
     }
   } else {
-    constexpr int TPK = R / 4;
-    constexpr int KBP = 256 / TPK;
-    constexpr int PASSES = (8 + KBP - 1) / KBP;
-    const int kb = tid / TPK, r4 = tid % TPK;
+    const int kb = tid / TR::TPK, r4 = tid % TR::TPK;
 #pragma unroll
-    for (int q = 0; q < PASSES; ++q) {
-      const int kbb = kb + q * KBP;
-      if (kbb < 8) {
+    for (int q = 0; q < TR::PASSES; ++q) {
+      const int kbb = kb + q * TR::KBP;
+      if (kbb < BK / 4) {
         float sc = 1.f;
         if (kscale) sc = kscale[(k0 + 4 * kbb) / kps];
         const float4 a = t.v[q * 4 + 0], b = t.v[q * 4 + 1], c = t.v[q * 4 + 2], d = t.v[q * 4 + 3];
@@ -116,12 +124,55 @@ __device__ __forceinline__ void store_tile(const TileRegs<R>& t, LT* __restrict_
   }
 }
 
-template <typename LT, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int klen) {
+// TM x TN register-blocked MFMA over one K-tile held in LDS
+template <typename LT, int TM, int TN, int BK> struct TileMma;
+template <int TM, int TN, int BK> struct TileMma<__bf16, TM, TN, BK> {
+  static __device__ __forceinline__ void run(f32x16 (&acc)[TM][TN], const __bf16* a_rows, const __bf16* b_rows, int h) {
+    constexpr int LD = BK + LdsT<__bf16>::PAD;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(a_rows + i * 32 * LD + 16 * ks + 8 * h);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(b_rows + j * 32 * LD + 16 * ks + 8 * h);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+};
+template <int TM, int TN, int BK> struct TileMma<float, TM, TN, BK> {
+  static __device__ __forceinline__ void run(f32x16 (&acc)[TM][TN], const float* a_rows, const float* b_rows, int h) {
+    constexpr int LD = BK + LdsT<float>::PAD;
+#pragma unroll
+    for (int ks = 0; ks < BK / 8; ++ks) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(a_rows + i * 32 * LD + 8 * ks + 4 * h);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(b_rows + j * 32 * LD + 8 * ks + 4 * h);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+};
+
+template <typename LT, int WM, int WN, int TM, int TN, int BK>
+__global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int klen, const bool vec_ok) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int LD = BK + LdsT<LT>::PAD;
-  __shared__ __attribute__((aligned(16))) LT As[BM * LD];
-  __shared__ __attribute__((aligned(16))) LT Bs[BN * LD];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LT* As = reinterpret_cast<LT*>(smem_raw);                  // [2][BM*LD]
+  LT* Bs = As + 2 * BM * LD;                                 // [2][BN*LD]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -138,86 +189,160 @@ __global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int kle
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  TileRegs<BM> ra;
-  TileRegs<BN> rb;
-  load_tile<BM>(ra, g.A, g.a_kc, g.lda, m0, g.M, kbeg, kend, false, tid);
-  load_tile<BN>(rb, g.B, g.b_kc, g.ldb, n0, g.N, kbeg, kend, g.b_ones != 0, tid);
+  TileRegs<BM, BK> ra;
+  TileRegs<BN, BK> rb;
+  load_tile<BM, BK>(ra, g.A, g.a_kc, g.lda, m0, g.M, kbeg, kend, false, tid);
+  load_tile<BN, BK>(rb, g.B, g.b_kc, g.ldb, n0, g.N, kbeg, kend, g.b_ones != 0, tid);
+  store_tile<BM, BK, LT>(ra, As, g.a_kc, g.a_op, g.kscale, g.k_per_scale, m0, g.M, kbeg, tid);
+  store_tile<BN, BK, LT>(rb, Bs, g.b_kc, g.b_op, nullptr, 1, n0, g.N, kbeg, tid);
+  __syncthreads();
 
+  int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    store_tile<BM, LT>(ra, As, g.a_kc, g.a_op, g.kscale, g.k_per_scale, m0, g.M, k0, tid);
-    store_tile<BN, LT>(rb, Bs, g.b_kc, g.b_op, nullptr, 1, n0, g.N, k0, tid);
-    __syncthreads();
-    if (k0 + BK < kend) {
-      load_tile<BM>(ra, g.A, g.a_kc, g.lda, m0, g.M, k0 + BK, kend, false, tid);
-      load_tile<BN>(rb, g.B, g.b_kc, g.ldb, n0, g.N, k0 + BK, kend, g.b_ones != 0, tid);
+    const bool more = k0 + BK < kend;
+    if (more) {
+      load_tile<BM, BK>(ra, g.A, g.a_kc, g.lda, m0, g.M, k0 + BK, kend, false, tid);
+      load_tile<BN, BK>(rb, g.B, g.b_kc, g.ldb, n0, g.N, k0 + BK, kend, g.b_ones != 0, tid);
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        mma32<LT>(acc[i][j], As + ((wm * TM + i) * 32 + r) * LD, Bs + ((wn * TN + j) * 32 + r) * LD, BK, h);
+    TileMma<LT, TM, TN, BK>::run(acc, As + buf * BM * LD + ((wm * TM) * 32 + r) * LD,
+                                 Bs + buf * BN * LD + ((wn * TN) * 32 + r) * LD, h);
+    if (more) {
+      store_tile<BM, BK, LT>(ra, As + (buf ^ 1) * BM * LD, g.a_kc, g.a_op, g.kscale, g.k_per_scale, m0, g.M, k0 + BK, tid);
+      store_tile<BN, BK, LT>(rb, Bs + (buf ^ 1) * BN * LD, g.b_kc, g.b_op, nullptr, 1, n0, g.N, k0 + BK, tid);
+    }
     __syncthreads();
+    buf ^= 1;
   }
 
-  // ---- epilogue --------------------------------------------------------------------------
+  // ---- epilogue: accumulators -> LDS (fp32 tile) -> coalesced float4 rows -------------------------
+  // The MFMA C layout gives each lane one column of 16 scattered rows (4-byte accesses, 128-B runs); going
+  // through LDS turns every HBM access of the epilogue (bias / residual / gelu' operand / output) into full
+  // 16-B-per-lane row segments.
+  constexpr int LDC = BN + 4;
+  float* Cs = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + r;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + (wm * TM + i) * 32 + mma32_row(e, h);
-        if (m >= g.M) continue;
-        float v = acc[i][j][e];
-        if (n < g.N) {
-          if (g.bias) v += g.bias[n];
-          if (g.rowscale) v *= g.rowscale[m / g.rows_per_scale];
-          if (g.gaux) v *= gelu_grad_f(g.gaux[(int64_t)m * g.ldg + n]);
-          if (g.res) v += g.res[(int64_t)m * g.ldr + n];
-          float* dst = g.C + (int64_t)m * g.ldc + n;
-          if (g.atomic_out) atomicAdd(dst, v); else *dst = v;
-        } else if (g.b_ones && n == g.N) {
-          atomicAdd(g.C2 + m, v);
+      for (int e = 0; e < 16; ++e)
+        Cs[((wm * TM + i) * 32 + mma32_row(e, h)) * LDC + (wn * TN + j) * 32 + r] = acc[i][j][e];
+  __syncthreads();
+  constexpr int TPRW = BN / 4, RPP = 256 / TPRW;
+  const int c4 = tid % TPRW;
+  const int n = n0 + 4 * c4;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool full = vec_ok && n + 3 < g.N;
+  if (full && g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + n);
+  for (int rr = tid / TPRW; rr < BM; rr += RPP) {
+    const int m = m0 + rr;
+    if (m >= g.M) break;
+    float4 v = *reinterpret_cast<const float4*>(Cs + rr * LDC + 4 * c4);
+    if (full) {
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      if (g.rowscale) {
+        const float sc = g.rowscale[m / g.rows_per_scale];
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      }
+      if (g.gaux) {
+        const float4 a = *reinterpret_cast<const float4*>(g.gaux + (int64_t)m * g.ldg + n);
+        v.x *= gelu_grad_f(a.x); v.y *= gelu_grad_f(a.y); v.z *= gelu_grad_f(a.z); v.w *= gelu_grad_f(a.w);
+      }
+      if (g.res) {
+        const float4 a = *reinterpret_cast<const float4*>(g.res + (int64_t)m * g.ldr + n);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      float* dst = g.C + (int64_t)m * g.ldc + n;
+      if (g.atomic_out) {
+        atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+      } else {
+        *reinterpret_cast<float4*>(dst) = v;
+      }
+    } else {
+      const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nn = n + q;
+        float val = e4[q];
+        if (nn < g.N) {
+          if (g.bias) val += g.bias[nn];
+          if (g.rowscale) val *= g.rowscale[m / g.rows_per_scale];
+          if (g.gaux) val *= gelu_grad_f(g.gaux[(int64_t)m * g.ldg + nn]);
+          if (g.res) val += g.res[(int64_t)m * g.ldr + nn];
+          float* dst = g.C + (int64_t)m * g.ldc + nn;
+          if (g.atomic_out) atomicAdd(dst, val); else *dst = val;
+        } else if (g.b_ones && nn == g.N) {
+          atomicAdd(g.C2 + m, val);
         }
       }
     }
   }
 }
 
-template <typename LT, int WM, int WN, int TM, int TN>
-int launch(const WmGemm& g, int ksplit, hipStream_t st) {
-  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+struct Plan { int tiles_m, tiles_n, ksplit, klen; };
+
+template <int BM, int BN, int BK>
+Plan make_plan(const WmGemm& g, int ksplit) {
   const int ncols = g.N + (g.b_ones ? 1 : 0);
-  const int tiles_n = (ncols + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  Plan p;
+  p.tiles_n = (ncols + BN - 1) / BN;
+  p.tiles_m = (g.M + BM - 1) / BM;
   if (ksplit <= 0) {
     ksplit = 1;
-    if (g.atomic_out) {
-      const int tiles = tiles_n * tiles_m;
+    if (g.atomic_out) {                       // weight-gradient GEMMs: tiny M x N, K = all tokens -> split K over the chip
+      const int tiles = p.tiles_n * p.tiles_m;
       const int want = (1024 + tiles - 1) / tiles;
-      const int maxs = (g.K + 255) / 256;
+      const int maxs = (g.K + 511) / 512;                      // at least 512 of K per workgroup (bounds atomic traffic)
       ksplit = want < 1 ? 1 : (want > maxs ? maxs : want);
       if (ksplit < 1) ksplit = 1;
     }
   }
-  int klen = (g.K + ksplit - 1) / ksplit;
-  klen = ((klen + BK - 1) / BK) * BK;
-  ksplit = (g.K + klen - 1) / klen;
-  dim3 grid(tiles_n, tiles_m, ksplit);
-  hipLaunchKernelGGL((gemm_kernel<LT, WM, WN, TM, TN>), grid, dim3(256), 0, st, g, klen);
+  p.klen = (g.K + ksplit - 1) / ksplit;
+  p.klen = ((p.klen + BK - 1) / BK) * BK;
+  p.ksplit = (g.K + p.klen - 1) / p.klen;
+  return p;
+}
+
+template <typename LT, int WM, int WN, int TM, int TN, int BK>
+int launch(const WmGemm& g, int ksplit, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int LD = BK + LdsT<LT>::PAD;
+  constexpr size_t stage = sizeof(LT) * 2 * (BM + BN) * LD, ctile = sizeof(float) * BM * (BN + 4);
+  constexpr size_t smem = stage > ctile ? stage : ctile;
+  const Plan p = make_plan<BM, BN, BK>(g, ksplit);
+  static bool attr = false;
+  if (!attr) {
+    if (smem > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<LT, WM, WN, TM, TN, BK>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  dim3 grid(p.tiles_n, p.tiles_m, p.ksplit);
+  const bool vec_ok = al16(g.C) && !(g.ldc & 3) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && !(g.ldr & 3))) &&
+                      (!g.gaux || (al16(g.gaux) && !(g.ldg & 3)));
+  hipLaunchKernelGGL((gemm_kernel<LT, WM, WN, TM, TN, BK>), grid, dim3(256), smem, st, g, p.klen, vec_ok);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
 
-template <typename LT>
+// Tile choice: the largest tile whose grid still gives every CU at least ~1.5 workgroups; the transformer's
+// coarse stages (M = B*256 or B*64 tokens) otherwise leave most of the 256 CUs idle behind 128x128 tiles.
+template <typename LT, int BK>
 int dispatch(const WmGemm& g, int ksplit, hipStream_t st) {
   const int ncols = g.N + (g.b_ones ? 1 : 0);
-  if (ncols <= 32) return launch<LT, 4, 1, 2, 1>(g, ksplit, st);
-  if (ncols <= 64) return launch<LT, 2, 2, 2, 1>(g, ksplit, st);
-  return launch<LT, 2, 2, 2, 2>(g, ksplit, st);
+  if (ncols <= 32) return launch<LT, 4, 1, 2, 1, BK>(g, ksplit, st);           // 256 x 32
+  const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((ncols + 127) / 128);
+  const int64_t t12864 = (int64_t)((g.M + 127) / 128) * ((ncols + 63) / 64);
+  const int64_t want = 384;
+  // weight-gradient GEMMs get ~4x more workgroups from split-K; more splits than that cost more in fp32 atomics
+  // (1.3 TB/s chip-wide) than the larger tile saves in operand re-reads (measured: 128x128 + deep split-K was slower)
+  const int ks = g.atomic_out ? 4 : 1;
+  if (ncols > 64 && t128 * ks >= want) return launch<LT, 2, 2, 2, 2, BK>(g, ksplit, st);       // 128 x 128
+  if (t12864 * ks >= want || g.M >= 32768) return launch<LT, 2, 2, 2, 1, BK>(g, ksplit, st);   // 128 x 64
+  return launch<LT, 2, 2, 1, 1, BK>(g, ksplit, st);                            // 64 x 64
 }
-
-inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
@@ -235,7 +360,10 @@ extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
   if (g.kscale && (g.k_per_scale <= 0 || (g.k_per_scale & 3))) return WM_EINVAL;
   if (g.rowscale && g.rows_per_scale <= 0) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (g.mode == 0) return dispatch<float>(g, g.ksplit, st);
-  if (g.mode == 1) return dispatch<__bf16>(g, g.ksplit, st);
+  if (g.mode == 0) return dispatch<float, 32>(g, g.ksplit, st);
+  if (g.mode == 1) {
+    static const int bk = [] { const char* e = getenv("WM_GEMM_BK"); return e ? atoi(e) : 64; }();
+    return bk == 32 ? dispatch<__bf16, 32>(g, g.ksplit, st) : dispatch<__bf16, 64>(g, g.ksplit, st);
+  }
   return WM_EINVAL;
 }

@@ -72,8 +72,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.
 // dgamma / dbeta: per-lane partial sums over the rows this wave visits, then LDS + atomics.
+constexpr int LNB_WAVES = 8;      // 512-thread blocks: 4x fewer same-address atomics per launch than 2048 x 256 threads
 template <int C>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(512) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ dgamma,
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   constexpr int L = (C / 4 < 64) ? C / 4 : 64;
   constexpr int V = C / (4 * L);
   constexpr int RPW = 64 / L;
-  __shared__ float red[2][4][C];
+  __shared__ float red[2][LNB_WAVES][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % L, rg = lane / L;
   float4 ag[V], ab[V], gm[V];
@@ -91,8 +92,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     ab[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     gm[q] = *reinterpret_cast<const float4*>(gamma + (q * L + sub) * 4);
   }
-  const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
-  for (int64_t row = ((int64_t)blockIdx.x * 4 + wave) * RPW + rg; row < rows; row += stride) {
+  const int64_t stride = (int64_t)gridDim.x * LNB_WAVES * RPW;
+  for (int64_t row = ((int64_t)blockIdx.x * LNB_WAVES + wave) * RPW + rg; row < rows; row += stride) {
     const float mu = mean[row], rs = rstd[row];
     float4 xh[V], g[V];
     float s1 = 0.f, s2 = 0.f;
@@ -142,9 +143,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
-    atomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+  for (int c = threadIdx.x; c < C; c += 512) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < LNB_WAVES; ++w) { sg += red[0][w][c]; sb += red[1][w][c]; }
+    atomicAdd(dgamma + c, sg);
+    atomicAdd(dbeta + c, sb);
   }
 }
 
@@ -192,10 +196,10 @@ template <int C>
 int ln_bwd_launch(const float* dy, const float* x, const float* g, const float* mean, const float* rstd,
                   const float* dres, float* dx, float* dg, float* db, int64_t rows, hipStream_t st) {
   constexpr int L = (C / 4 < 64) ? C / 4 : 64;
-  constexpr int RPB = 4 * (64 / L);
+  constexpr int RPB = LNB_WAVES * (64 / L);
   int64_t blocks = (rows + RPB - 1) / RPB;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL((ln_bwd_kernel<C>), dim3((unsigned)blocks), dim3(256), 0, st, dy, x, g, mean, rstd, dres,
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL((ln_bwd_kernel<C>), dim3((unsigned)blocks), dim3(512), 0, st, dy, x, g, mean, rstd, dres,
                      dx, dg, db, rows);
   WM_CHECK_LAUNCH();
   return WM_OK;

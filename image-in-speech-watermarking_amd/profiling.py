@@ -57,17 +57,38 @@ COST = {
 
 
 class KernelTimer:
-    def __init__(self):
+    def __init__(self, detail=False):
         self.records = collections.defaultdict(list)      # key -> [(start_evt, stop_evt, flops, bytes)]
         self._saved = {}
+        self.detail = detail                               # key GEMMs by layout and shape as well
 
     def _key(self, name, args, kwargs):
         if name == "gemm":
             M, N, K = args[3:6]
             mode = kwargs.get("mode", 0)
             n_eff = N + (1 if kwargs.get("b_ones") else 0)
-            tile = "256x32" if n_eff <= 32 else ("128x64" if n_eff <= 64 else "128x128")
+            cd = lambda a, b: (a + b - 1) // b
+            ks = 4 if kwargs.get("atomic_out") else 1
+            if n_eff <= 32:
+                tile = "256x32"
+            elif n_eff > 64 and cd(M, 128) * cd(n_eff, 128) * ks >= 384:
+                tile = "128x128"
+            elif cd(M, 128) * cd(n_eff, 64) * ks >= 384 or M >= 32768:
+                tile = "128x64"
+            else:
+                tile = "64x64"                      # mirrors dispatch() in csrc/gemm.hip
+            if self.detail:
+                lay = {(1, 1): "fwd", (1, 0): "dX", (0, 0): "dW"}.get((args[9] if len(args) > 9 else kwargs.get("a_kc", 1),
+                                                                     args[10] if len(args) > 10 else kwargs.get("b_kc", 1)), "?")
+                return f"gemm_{'bf16' if mode else 'f32'}_{tile}_{lay}_M{M}_N{N}_K{K}", mode
             return f"gemm_{'bf16' if mode else 'f32'}_{tile}", mode
+        if name in ("conv_fwd", "conv_bwd") and self.detail:
+            d = args[0]
+            return f"{name}_Cin{d.Cin}_Cout{d.Cout}_H{d.H}_k{d.KH}{'_T' if d.transposed else ''}", None
+        if self.detail and name in ("dwconv_bwd", "dwconv_fwd", "layernorm_bwd", "winattn_bwd", "winattn_fwd"):
+            sz = args[0].numel()
+            tag = f"{name}_n{sz}"
+            return (tag + ("_bf16" if name.startswith("winattn") and args[-1] else "")), (args[-1] if name.startswith("winattn") else None)
         if name.startswith("winattn"):
             return f"{name}_{'bf16' if args[-1] else 'f32'}", args[-1]
         return name, None
