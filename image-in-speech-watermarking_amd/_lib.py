@@ -23,7 +23,8 @@ class WmGemm(C.Structure):
                 ("kscale", c_f), ("k_per_scale", c_i32),
                 ("gaux", c_f), ("ldg", c_i64),
                 ("b_ones", c_i32), ("C2", c_f),
-                ("atomic_out", c_i32), ("ksplit", c_i32), ("mode", c_i32)]
+                ("atomic_out", c_i32), ("ksplit", c_i32), ("mode", c_i32),
+                ("a_bf16", c_i32), ("b_bf16", c_i32), ("c_bf16", c_i32), ("gaux_bf16", c_i32)]
 
 
 class WmConv(C.Structure):
@@ -39,18 +40,19 @@ class WmAttack(C.Structure):
 _SIGS = {
     "wm_abi_version": [],
     "wm_gemm": [C.POINTER(WmGemm), c_f],
-    "wm_layernorm_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f],
-    "wm_layernorm_bwd": [c_f] * 10 + [c_i64, c_i32, c_i32, c_i32, c_f],
-    "wm_winattn_fwd": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
-    "wm_winattn_bwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
-    "wm_dwconv_fwd": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_f],
-    "wm_dwconv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_f],
-    "wm_im2col_4x4s2": [c_f, c_f, c_i32, c_i32, c_i32, c_f],
-    "wm_col2im_4x4s2": [c_f, c_f, c_i32, c_i32, c_i32, c_f],
-    "wm_pixel_shuffle2": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i64, c_i32, c_f],
-    "wm_pixel_unshuffle2": [c_f, c_f, c_i32, c_i32, c_i32, c_i64, c_i32, c_f],
+    "wm_layernorm_fwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f],
+    "wm_layernorm_bwd": [c_f, c_i32] + [c_f] * 9 + [c_i64, c_i32, c_i32, c_i32, c_f],
+    "wm_winattn_fwd": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_winattn_bwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_dwconv_fwd": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_dwconv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_im2col_4x4s2": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_col2im_4x4s2": [c_f, c_i32, c_f, c_i32, c_i32, c_i32, c_f],
+    "wm_pixel_shuffle2": [c_f, c_i32, c_f, c_f, c_i32, c_i32, c_i32, c_i64, c_i32, c_f],
+    "wm_pixel_unshuffle2": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_f],
     "wm_copy_cols": [c_f, c_i64, c_i32, c_f, c_i64, c_i32, c_i64, c_i32, c_i32, c_f],
-    "wm_strided3": [c_f, c_f, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_f],
+    "wm_strided3": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_f],
+    "wm_cast_bf16": [c_f, c_f, c_i64, c_f],
     "wm_msg_expand_fwd": [c_f, c_f, c_i32, c_f],
     "wm_msg_expand_bwd": [c_f, c_f, c_i32, c_f],
     "wm_conv_fwd": [C.POINTER(WmConv), c_f, c_f, c_f, c_f, c_f],
@@ -99,7 +101,7 @@ def check(rc, what):
 
 
 def ptr(t):
-    """Device pointer of a contiguous fp32/int64 CUDA tensor (None -> NULL)."""
+    """Device pointer of a contiguous fp32/bf16/int64 CUDA tensor (None -> NULL)."""
     if t is None:
         return None
     if not t.is_cuda:

@@ -38,26 +38,26 @@ __device__ __forceinline__ int rel_index(int i, int j) {
 }
 
 // dst[tok][0..31] = scale * src[row(tok)][col0 .. col0+31]
-template <typename LT>
-__device__ __forceinline__ void stage_rows(LT* dst, const float* __restrict__ src, int64_t ld, int col0,
+template <typename LT, typename ST>
+__device__ __forceinline__ void stage_rows(LT* dst, const ST* __restrict__ src, int64_t ld, int col0,
                                            const WinGeom& g, int b, int wy, int wx, float scale, int lane) {
   constexpr int LDK = AttnDims<LT>::LDK;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int idx = lane + 64 * it, tok = idx >> 3, f4 = idx & 7;
-    const float4 v = *reinterpret_cast<const float4*>(src + g.token_row(b, wy, wx, tok) * ld + col0 + 4 * f4);
+    const float4 v = IO<ST>::ld4(src + g.token_row(b, wy, wx, tok) * ld + col0 + 4 * f4);
     LdsT<LT>::store4(dst + tok * LDK + 4 * f4, v.x * scale, v.y * scale, v.z * scale, v.w * scale);
   }
 }
 // dst[e][tok] = scale * src[row(tok)][col0 + e]
-template <typename LT>
-__device__ __forceinline__ void stage_cols(LT* dst, const float* __restrict__ src, int64_t ld, int col0,
+template <typename LT, typename ST>
+__device__ __forceinline__ void stage_cols(LT* dst, const ST* __restrict__ src, int64_t ld, int col0,
                                            const WinGeom& g, int b, int wy, int wx, float scale, int lane) {
   constexpr int LDT = AttnDims<LT>::LDT;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int idx = lane + 64 * it, tok = idx & 63, f4 = idx >> 6;
-    const float4 v = *reinterpret_cast<const float4*>(src + g.token_row(b, wy, wx, tok) * ld + col0 + 4 * f4);
+    const float4 v = IO<ST>::ld4(src + g.token_row(b, wy, wx, tok) * ld + col0 + 4 * f4);
     LdsT<LT>::store1(dst + (4 * f4 + 0) * LDT + tok, v.x * scale);
     LdsT<LT>::store1(dst + (4 * f4 + 1) * LDT + tok, v.y * scale);
     LdsT<LT>::store1(dst + (4 * f4 + 2) * LDT + tok, v.z * scale);
@@ -106,9 +106,9 @@ __device__ __forceinline__ void softmax_row(const float* S, int lane, float (&p)
   for (int j = 0; j < 64; ++j) p[j] *= inv;
 }
 
-template <typename LT>
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ table,
-                                                      float* __restrict__ out, WinGeom g, int B) {
+template <typename LT, typename ST>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const ST* __restrict__ qkv, const float* __restrict__ table,
+                                                      ST* __restrict__ out, WinGeom g, int B) {
   constexpr int LDK = AttnDims<LT>::LDK, LDT = AttnDims<LT>::LDT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   LT* Qs = reinterpret_cast<LT*>(smem);                       // [64][LDK]; later P [64][LDT] over Qs+Ks
@@ -125,9 +125,9 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
   const int64_t ld = 3 * (int64_t)g.C;
   const float scale = 0.17677669529663687f;                   // 32^-0.5 (model.py:489)
 
-  stage_rows<LT>(Qs, qkv, ld, head * 32, g, b, wy, wx, scale, lane);
-  stage_rows<LT>(Ks, qkv, ld, g.C + head * 32, g, b, wy, wx, 1.0f, lane);
-  stage_cols<LT>(Vt, qkv, ld, 2 * g.C + head * 32, g, b, wy, wx, 1.0f, lane);
+  stage_rows<LT, ST>(Qs, qkv, ld, head * 32, g, b, wy, wx, scale, lane);
+  stage_rows<LT, ST>(Ks, qkv, ld, g.C + head * 32, g, b, wy, wx, 1.0f, lane);
+  stage_cols<LT, ST>(Vt, qkv, ld, 2 * g.C + head * 32, g, b, wy, wx, 1.0f, lane);
   __syncthreads();
   scores_to_lds<LT>(S, Qs, Ks, table, g, wy, wx, head, lane);
   __syncthreads();
@@ -146,14 +146,14 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int i = ti * 32 + mma32_row(e, h);
-      out[g.token_row(b, wy, wx, i) * g.C + head * 32 + r] = acc[e];
+      IO<ST>::st1(out + g.token_row(b, wy, wx, i) * g.C + head * 32 + r, acc[e]);
     }
   }
 }
 
-template <typename LT>
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ table,
-                                                      const float* __restrict__ dout, float* __restrict__ dqkv,
+template <typename LT, typename ST>
+__global__ __launch_bounds__(64) void attn_bwd_kernel(const ST* __restrict__ qkv, const float* __restrict__ table,
+                                                      const ST* __restrict__ dout, ST* __restrict__ dqkv,
                                                       float* __restrict__ dtable, WinGeom g, int B) {
   constexpr int LDK = AttnDims<LT>::LDK, LDT = AttnDims<LT>::LDT, SMALL = AttnDims<LT>::SMALL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -181,16 +181,16 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
     const int b = w / (g.nw * g.nw), wr = w - b * g.nw * g.nw, wy = wr / g.nw, wx = wr - wy * g.nw;
     __syncthreads();
     // P1: S = softmax input
-    stage_rows<LT>(T0, qkv, ld, head * 32, g, b, wy, wx, scale, lane);
-    stage_rows<LT>(T1, qkv, ld, g.C + head * 32, g, b, wy, wx, 1.0f, lane);
+    stage_rows<LT, ST>(T0, qkv, ld, head * 32, g, b, wy, wx, scale, lane);
+    stage_rows<LT, ST>(T1, qkv, ld, g.C + head * 32, g, b, wy, wx, 1.0f, lane);
     __syncthreads();
     scores_to_lds<LT>(S, T0, T1, table, g, wy, wx, head, lane);
     __syncthreads();
     float p[64];
     softmax_row(S, lane, p);
     // P2: dP = dO V^T
-    stage_rows<LT>(T0, dout, (int64_t)g.C, head * 32, g, b, wy, wx, 1.0f, lane);
-    stage_rows<LT>(T1, qkv, ld, 2 * g.C + head * 32, g, b, wy, wx, 1.0f, lane);
+    stage_rows<LT, ST>(T0, dout, (int64_t)g.C, head * 32, g, b, wy, wx, 1.0f, lane);
+    stage_rows<LT, ST>(T1, qkv, ld, 2 * g.C + head * 32, g, b, wy, wx, 1.0f, lane);
     __syncthreads();
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
@@ -223,9 +223,9 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
       for (int j = 0; j < 64; j += 4) LdsT<LT>::store4(dS + lane * LDT + j, dp[j], dp[j + 1], dp[j + 2], dp[j + 3]);
     }
     // P4: dQ = scale * dS K ; dK = dS^T Qs ; dV = P^T dO
-    stage_cols<LT>(T0, qkv, ld, g.C + head * 32, g, b, wy, wx, 1.0f, lane);       // K^T  [e][j]
-    stage_cols<LT>(T1, qkv, ld, head * 32, g, b, wy, wx, scale, lane);             // Qs^T [e][i]
-    stage_cols<LT>(T2, dout, (int64_t)g.C, head * 32, g, b, wy, wx, 1.0f, lane);   // dO^T [e][i]
+    stage_cols<LT, ST>(T0, qkv, ld, g.C + head * 32, g, b, wy, wx, 1.0f, lane);       // K^T  [e][j]
+    stage_cols<LT, ST>(T1, qkv, ld, head * 32, g, b, wy, wx, scale, lane);             // Qs^T [e][i]
+    stage_cols<LT, ST>(T2, dout, (int64_t)g.C, head * 32, g, b, wy, wx, 1.0f, lane);   // dO^T [e][i]
     __syncthreads();
 #pragma unroll
     for (int which = 0; which < 3; ++which) {
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int t = ti * 32 + mma32_row(e, h);
-          dqkv[g.token_row(b, wy, wx, t) * ld + which * g.C + head * 32 + r] = acc[e] * osc;
+          IO<ST>::st1(dqkv + g.token_row(b, wy, wx, t) * ld + which * g.C + head * 32 + r, acc[e] * osc);
         }
       }
     }
@@ -264,59 +264,62 @@ template <typename LT> size_t bwd_smem() {
   return sizeof(LT) * (3 * AttnDims<LT>::SMALL + 64 * AttnDims<LT>::LDT) + sizeof(float) * 2 * 64 * LDS_S;
 }
 
-bool geom_ok(const float* a, const float* b, int B, int hw, int C, int shift) {
+bool geom_ok(const void* a, const void* b, int B, int hw, int C, int shift) {
   return a && b && B > 0 && hw >= 8 && (hw & 7) == 0 && C >= 32 && (C & 31) == 0 && shift >= 0 && shift < 8 &&
          !(shift > 0 && hw <= 8);
 }
 
-}  // namespace
 
-extern "C" int wm_winattn_fwd(const float* qkv, const float* bias_table, float* out, int32_t B, int32_t hw,
-                              int32_t C, int32_t shift, int32_t mode, void* stream) {
-  if (!geom_ok(qkv, bias_table, B, hw, C, shift) || !out) return WM_EINVAL;
-  WinGeom g{hw, shift, hw / 8, C, C / 32};
+
+template <typename LT, typename ST>
+int attn_fwd_launch(const void* qkv, const float* table, void* out, const WinGeom& g, int B, hipStream_t st) {
   dim3 grid(B * g.nw * g.nw, g.heads);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (mode == 0) {
-    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(64), fwd_smem<float>(), st, qkv, bias_table, out, g, B);
-  } else if (mode == 1) {
-    hipLaunchKernelGGL(attn_fwd_kernel<__bf16>, grid, dim3(64), fwd_smem<__bf16>(), st, qkv, bias_table, out, g, B);
-  } else {
-    return WM_EINVAL;
-  }
+  hipLaunchKernelGGL((attn_fwd_kernel<LT, ST>), grid, dim3(64), fwd_smem<LT>(), st, static_cast<const ST*>(qkv), table,
+                     static_cast<ST*>(out), g, B);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
-
-extern "C" int wm_winattn_bwd(const float* qkv, const float* bias_table, const float* dout, float* dqkv,
-                              float* dbias_table, int32_t B, int32_t hw, int32_t C, int32_t shift, int32_t mode,
-                              void* stream) {
-  if (!geom_ok(qkv, bias_table, B, hw, C, shift) || !dout || !dqkv || !dbias_table) return WM_EINVAL;
-  WinGeom g{hw, shift, hw / 8, C, C / 32};
+template <typename LT, typename ST>
+int attn_bwd_launch(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, const WinGeom& g,
+                    int B, hipStream_t st) {
   const int nwin = B * g.nw * g.nw;
   int chunks = 2048 / g.heads;
   if (chunks < 64) chunks = 64;
   if (chunks > nwin) chunks = nwin;
-  dim3 grid(chunks, g.heads);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   static bool attr_done = false;
-  if (!attr_done) {
-    // > 64 KiB of dynamic LDS needs an explicit opt-in on the fp32 instantiation
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<float>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_smem<float>());
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<__bf16>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_smem<__bf16>());
+  if (!attr_done) {      // > 64 KiB of dynamic LDS needs an explicit opt-in
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<LT, ST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_smem<LT>());
     attr_done = true;
   }
-  if (mode == 0) {
-    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, dim3(64), bwd_smem<float>(), st, qkv, bias_table, dout, dqkv,
-                       dbias_table, g, B);
-  } else if (mode == 1) {
-    hipLaunchKernelGGL(attn_bwd_kernel<__bf16>, grid, dim3(64), bwd_smem<__bf16>(), st, qkv, bias_table, dout,
-                       dqkv, dbias_table, g, B);
-  } else {
-    return WM_EINVAL;
-  }
+  hipLaunchKernelGGL((attn_bwd_kernel<LT, ST>), dim3(chunks, g.heads), dim3(64), bwd_smem<LT>(), st,
+                     static_cast<const ST*>(qkv), table, static_cast<const ST*>(dout), static_cast<ST*>(dqkv), dtable, g, B);
   WM_CHECK_LAUNCH();
   return WM_OK;
+}
+
+}  // namespace
+
+extern "C" int wm_winattn_fwd(const void* qkv, const float* bias_table, void* out, int32_t io_bf16, int32_t B,
+                              int32_t hw, int32_t C, int32_t shift, int32_t mode, void* stream) {
+  if (!geom_ok(qkv, bias_table, B, hw, C, shift) || !out || (io_bf16 && mode != 1)) return WM_EINVAL;
+  WinGeom g{hw, shift, hw / 8, C, C / 32};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (mode == 0) return attn_fwd_launch<float, float>(qkv, bias_table, out, g, B, st);
+  if (mode == 1 && io_bf16) return attn_fwd_launch<__bf16, __bf16>(qkv, bias_table, out, g, B, st);
+  if (mode == 1) return attn_fwd_launch<__bf16, float>(qkv, bias_table, out, g, B, st);
+  return WM_EINVAL;
+}
+
+extern "C" int wm_winattn_bwd(const void* qkv, const float* bias_table, const void* dout, void* dqkv,
+                              float* dbias_table, int32_t io_bf16, int32_t B, int32_t hw, int32_t C, int32_t shift,
+                              int32_t mode, void* stream) {
+  if (!geom_ok(qkv, bias_table, B, hw, C, shift) || !dout || !dqkv || !dbias_table || (io_bf16 && mode != 1))
+    return WM_EINVAL;
+  WinGeom g{hw, shift, hw / 8, C, C / 32};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (mode == 0) return attn_bwd_launch<float, float>(qkv, bias_table, dout, dqkv, dbias_table, g, B, st);
+  if (mode == 1 && io_bf16) return attn_bwd_launch<__bf16, __bf16>(qkv, bias_table, dout, dqkv, dbias_table, g, B, st);
+  if (mode == 1) return attn_bwd_launch<__bf16, float>(qkv, bias_table, dout, dqkv, dbias_table, g, B, st);
+  return WM_EINVAL;
 }

@@ -61,6 +61,32 @@ template <> struct LdsT<__bf16> {
   __device__ static __forceinline__ void store1(__bf16* p, float a) { *p = (__bf16)a; }
 };
 
+// ---- HBM storage types: float, or bf16 for the wide activations in bf16 mode -------------------------
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
+  bf16x4 t = {(__bf16)a, (__bf16)b, (__bf16)0.f, (__bf16)0.f};
+  return reinterpret_cast<const uint2&>(t).x;
+}
+template <typename T> struct IO;
+template <> struct IO<float> {
+  static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+  static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+  static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+};
+template <> struct IO<__bf16> {
+  static __device__ __forceinline__ float4 ld4(const __bf16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y));
+  }
+  static __device__ __forceinline__ void st4(__bf16* p, float4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+  }
+  static __device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
+  static __device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
+};
+
 // acc(32x32) += A(32 x kcount) * B(kcount x 32).
 // a_row / b_row point at THIS LANE's row (tile_row0 + (lane & 31)) of a K-contiguous LDS image;
 // B is held "n-major" (Bs[n][k]) so both operands are read the same way.

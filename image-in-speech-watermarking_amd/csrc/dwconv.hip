@@ -12,7 +12,8 @@ constexpr int TP = 8;              // tile is TP x TP pixels
 constexpr int HP = TP + 2;         // with halo
 constexpr int TC = 64;             // channels per workgroup
 
-__device__ __forceinline__ void load_halo_tile(float* tile, const float* __restrict__ src, int b, int ty, int tx,
+template <typename ST>
+__device__ __forceinline__ void load_halo_tile(float* tile, const ST* __restrict__ src, int b, int ty, int tx,
                                                int hw, int Ch, int cbase, bool gelu, int tid) {
   for (int idx = tid; idx < HP * HP * (TC / 4); idx += 256) {
     const int pix = idx / (TC / 4), c4 = idx % (TC / 4);
@@ -20,15 +21,16 @@ __device__ __forceinline__ void load_halo_tile(float* tile, const float* __restr
     const int gy = ty * TP + ly - 1, gx = tx * TP + lx - 1;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gy >= 0 && gy < hw && gx >= 0 && gx < hw) {
-      v = *reinterpret_cast<const float4*>(src + (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4);
+      v = IO<ST>::ld4(src + (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4);
       if (gelu) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
     }
     *reinterpret_cast<float4*>(tile + pix * TC + 4 * c4) = v;
   }
 }
 
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ h1, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ h2,
+template <typename ST>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ST* __restrict__ h1, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, ST* __restrict__ h2,
                                                          int B, int hw, int Ch) {
   __shared__ __attribute__((aligned(16))) float tile[HP * HP * TC];
   const int tid = threadIdx.x, nt = hw / TP;
@@ -57,14 +59,14 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
         o[2] += wr[2][dy * 3 + dx] * a.z; o[3] += wr[3][dy * 3 + dx] * a.w;
       }
     const int gy = ty * TP + py, gx = tx * TP + px;
-    *reinterpret_cast<float4*>(h2 + (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4) =
-        make_float4(o[0], o[1], o[2], o[3]);
+    IO<ST>::st4(h2 + (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
 // dh1 = gelu'(h1) * sum_k w[k] * dh2[p - off_k];  dw[c][k] += sum_p dh2[p] * gelu(h1)[p + off_k]; db += sum_p dh2
-__global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(const float* __restrict__ h1, const float* __restrict__ dh2,
-                                                         const float* __restrict__ w, float* __restrict__ dh1,
+template <typename ST>
+__global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(const ST* __restrict__ h1, const ST* __restrict__ dh2,
+                                                         const float* __restrict__ w, ST* __restrict__ dh1,
                                                          float* __restrict__ dw, float* __restrict__ db, int B,
                                                          int hw, int Ch) {
   __shared__ __attribute__((aligned(16))) float ta[HP * HP * TC];      // gelu(h1) with halo
@@ -105,9 +107,9 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(const float* __restr
       ab[0] += gc.x; ab[1] += gc.y; ab[2] += gc.z; ab[3] += gc.w;
       const int gy = ty * TP + py, gx = tx * TP + px;
       const int64_t off = (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4;
-      const float4 hv = *reinterpret_cast<const float4*>(h1 + off);
-      *reinterpret_cast<float4*>(dh1 + off) = make_float4(o[0] * gelu_grad_f(hv.x), o[1] * gelu_grad_f(hv.y),
-                                                           o[2] * gelu_grad_f(hv.z), o[3] * gelu_grad_f(hv.w));
+      const float4 hv = IO<ST>::ld4(h1 + off);
+      IO<ST>::st4(dh1 + off, make_float4(o[0] * gelu_grad_f(hv.x), o[1] * gelu_grad_f(hv.y), o[2] * gelu_grad_f(hv.z),
+                                          o[3] * gelu_grad_f(hv.w)));
     }
   }
 #pragma unroll
@@ -128,22 +130,32 @@ bool ok(int B, int hw, int Ch) { return B > 0 && hw >= 8 && (hw & 7) == 0 && Ch 
 
 }  // namespace
 
-extern "C" int wm_dwconv_fwd(const float* h1, const float* w, const float* b, float* h2, int32_t B, int32_t hw,
-                             int32_t Ch, void* stream) {
+extern "C" int wm_dwconv_fwd(const void* h1, const float* w, const float* b, void* h2, int32_t io_bf16, int32_t B,
+                             int32_t hw, int32_t Ch, void* stream) {
   if (!h1 || !w || !b || !h2 || !ok(B, hw, Ch)) return WM_EINVAL;
   const int nt = hw / TP;
-  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(B * nt * nt, Ch / TC), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     h1, w, b, h2, B, hw, Ch);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (io_bf16)
+    hipLaunchKernelGGL(dwconv_fwd_kernel<__bf16>, dim3(B * nt * nt, Ch / TC), dim3(256), 0, st,
+                       static_cast<const __bf16*>(h1), w, b, static_cast<__bf16*>(h2), B, hw, Ch);
+  else
+    hipLaunchKernelGGL(dwconv_fwd_kernel<float>, dim3(B * nt * nt, Ch / TC), dim3(256), 0, st,
+                       static_cast<const float*>(h1), w, b, static_cast<float*>(h2), B, hw, Ch);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
 
-extern "C" int wm_dwconv_bwd(const float* h1, const float* dh2, const float* w, float* dh1, float* dw, float* db,
-                             int32_t B, int32_t hw, int32_t Ch, void* stream) {
+extern "C" int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, void* dh1, float* dw, float* db,
+                             int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream) {
   if (!h1 || !dh2 || !w || !dh1 || !dw || !db || !ok(B, hw, Ch)) return WM_EINVAL;
   const int nt = hw / TP;
-  hipLaunchKernelGGL(dwconv_bwd_kernel, dim3(B * nt, Ch / TC), dim3(256), 0, static_cast<hipStream_t>(stream), h1,
-                     dh2, w, dh1, dw, db, B, hw, Ch);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (io_bf16)
+    hipLaunchKernelGGL(dwconv_bwd_kernel<__bf16>, dim3(B * nt, Ch / TC), dim3(256), 0, st, static_cast<const __bf16*>(h1),
+                       static_cast<const __bf16*>(dh2), w, static_cast<__bf16*>(dh1), dw, db, B, hw, Ch);
+  else
+    hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(B * nt, Ch / TC), dim3(256), 0, st, static_cast<const float*>(h1),
+                       static_cast<const float*>(dh2), w, static_cast<float*>(dh1), dw, db, B, hw, Ch);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

@@ -124,6 +124,153 @@ __device__ __forceinline__ void store_tile(const TileRegs<R, BK>& t, LT* __restr
   }
 }
 
+// ---- bf16 operands in HBM (wide activations / weight copies in bf16 mode): 16-byte loads of 8 elements ----------
+template <int R, int BK> struct TileRegsH {
+  static constexpr int TPR = BK / 8;                       // threads per row (K-contiguous)
+  static constexpr int RPP = 256 / TPR;
+  static constexpr int KC_N = (R + RPP - 1) / RPP;
+  static constexpr int NBLK = (R / 8) * (BK / 8);          // 8x8 blocks (row-contiguous source)
+  static constexpr int BPT = (NBLK + 255) / 256;           // blocks per thread
+  static constexpr int N = KC_N > 8 * BPT ? KC_N : 8 * BPT;
+  uint4 v[N];
+};
+
+template <int R, int BK>
+__device__ __forceinline__ void load_tile_h(TileRegsH<R, BK>& t, const __bf16* __restrict__ p, bool kc, int64_t ld,
+                                            int row0, int rmax, int k0, int kend, bool ones, int tid) {
+  using TR = TileRegsH<R, BK>;
+  const uint4 zero = make_uint4(0, 0, 0, 0), one = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+  if (kc) {
+    const int r = tid / TR::TPR, kq = tid % TR::TPR;
+    const int k = k0 + 8 * kq;
+#pragma unroll
+    for (int q = 0; q < TR::KC_N; ++q) {
+      const int rl = r + TR::RPP * q, row = row0 + rl;
+      uint4 v = zero;
+      if (rl < R && k < kend) {
+        if (row < rmax) v = *reinterpret_cast<const uint4*>(p + (int64_t)row * ld + k);
+        else if (ones && row == rmax) v = one;
+      }
+      t.v[q] = v;
+    }
+  } else {
+#pragma unroll
+    for (int bq = 0; bq < TR::BPT; ++bq) {
+      const int blk = tid + 256 * bq;
+      const int kb = blk / (R / 8), r8 = blk % (R / 8);
+      const int row = row0 + 8 * r8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = k0 + 8 * kb + i;
+        uint4 v = zero;
+        if (blk < TR::NBLK && k < kend) {
+          const __bf16* src = p + (int64_t)k * ld + row;
+          if (row + 7 < rmax) {
+            v = *reinterpret_cast<const uint4*>(src);
+          } else {
+            uint16_t e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int rr = row + j;
+              e[j] = rr < rmax ? reinterpret_cast<const uint16_t*>(src)[j] : ((ones && rr == rmax) ? 0x3F80 : 0);
+            }
+            v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+          }
+        }
+        t.v[bq * 8 + i] = v;
+      }
+    }
+  }
+}
+
+template <int R, int BK>
+__device__ __forceinline__ void store_tile_h(const TileRegsH<R, BK>& t, __bf16* __restrict__ s, bool kc, int op,
+                                             const float* __restrict__ kscale, int kps, int row0, int rmax, int k0,
+                                             int tid) {
+  using TR = TileRegsH<R, BK>;
+  constexpr int LD = BK + LdsT<__bf16>::PAD;
+  if (kc) {
+    const int r = tid / TR::TPR, kq = tid % TR::TPR;
+    float sc = 1.f;
+    const bool scaled = kscale != nullptr;
+    if (scaled) sc = kscale[(k0 + 8 * kq) / kps];
+#pragma unroll
+    for (int q = 0; q < TR::KC_N; ++q) {
+      const int rl = r + TR::RPP * q;
+      if (rl < R) {
+        uint4 v = t.v[q];
+        const bool real = row0 + rl < rmax;
+        if ((op && real) || scaled) {
+          uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float a = bf_lo(w[j]), b = bf_hi(w[j]);
+            if (op && real) { a = apply_op(a, op); b = apply_op(b, op); }
+            w[j] = pack_bf2(a * sc, b * sc);
+          }
+          v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *reinterpret_cast<uint4*>(s + rl * LD + 8 * kq) = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int bq = 0; bq < TR::BPT; ++bq) {
+      const int blk = tid + 256 * bq;
+      if (blk < TR::NBLK) {
+        const int kb = blk / (R / 8), r8 = blk % (R / 8);
+        float sc = 1.f;
+        const bool scaled = kscale != nullptr;
+        if (scaled) sc = kscale[(k0 + 8 * kb) / kps];
+        // 8x8 transpose: source register i holds rows 8*r8..+7 at k = 8*kb + i
+        uint32_t src[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { src[i][0] = t.v[bq * 8 + i].x; src[i][1] = t.v[bq * 8 + i].y; src[i][2] = t.v[bq * 8 + i].z; src[i][3] = t.v[bq * 8 + i].w; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                       // output row j: k = 0..7
+          const int rl = 8 * r8 + j;
+          const bool real = row0 + rl < rmax;
+          uint32_t o[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const uint32_t a = src[2 * kk][j >> 1], b = src[2 * kk + 1][j >> 1];
+            uint32_t lo = (j & 1) ? (a >> 16) : (a & 0xffffu);
+            uint32_t hi = (j & 1) ? (b & 0xffff0000u) : (b << 16);
+            if ((op && real) || scaled) {
+              float fa = __uint_as_float(lo << 16), fb = __uint_as_float(hi);
+              if (op && real) { fa = apply_op(fa, op); fb = apply_op(fb, op); }
+              o[kk] = pack_bf2(fa * sc, fb * sc);
+            } else {
+              o[kk] = lo | hi;
+            }
+          }
+          *reinterpret_cast<uint4*>(s + rl * LD + 8 * kb) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    }
+  }
+}
+
+// operand stager: picks the float or bf16 global->LDS path from the source type
+template <typename ST, int R, int BK, typename LT> struct Stager {
+  TileRegs<R, BK> regs;
+  __device__ __forceinline__ void load(const void* p, bool kc, int64_t ld, int row0, int rmax, int k0, int kend, bool ones, int tid) {
+    load_tile<R, BK>(regs, static_cast<const float*>(p), kc, ld, row0, rmax, k0, kend, ones, tid);
+  }
+  __device__ __forceinline__ void store(LT* s, bool kc, int op, const float* ks, int kps, int row0, int rmax, int k0, int tid) const {
+    store_tile<R, BK, LT>(regs, s, kc, op, ks, kps, row0, rmax, k0, tid);
+  }
+};
+template <int R, int BK> struct Stager<__bf16, R, BK, __bf16> {
+  TileRegsH<R, BK> regs;
+  __device__ __forceinline__ void load(const void* p, bool kc, int64_t ld, int row0, int rmax, int k0, int kend, bool ones, int tid) {
+    load_tile_h<R, BK>(regs, static_cast<const __bf16*>(p), kc, ld, row0, rmax, k0, kend, ones, tid);
+  }
+  __device__ __forceinline__ void store(__bf16* s, bool kc, int op, const float* ks, int kps, int row0, int rmax, int k0, int tid) const {
+    store_tile_h<R, BK>(regs, s, kc, op, ks, kps, row0, rmax, k0, tid);
+  }
+};
+
 // TM x TN register-blocked MFMA over one K-tile held in LDS
 template <typename LT, int TM, int TN, int BK> struct TileMma;
 template <int TM, int TN, int BK> struct TileMma<__bf16, TM, TN, BK> {
@@ -166,7 +313,7 @@ template <int TM, int TN, int BK> struct TileMma<float, TM, TN, BK> {
   }
 };
 
-template <typename LT, int WM, int WN, int TM, int TN, int BK>
+template <typename LT, typename AT, typename BT, int WM, int WN, int TM, int TN, int BK>
 __global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int klen, const bool vec_ok) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int LD = BK + LdsT<LT>::PAD;
@@ -189,26 +336,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int kle
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  TileRegs<BM, BK> ra;
-  TileRegs<BN, BK> rb;
-  load_tile<BM, BK>(ra, g.A, g.a_kc, g.lda, m0, g.M, kbeg, kend, false, tid);
-  load_tile<BN, BK>(rb, g.B, g.b_kc, g.ldb, n0, g.N, kbeg, kend, g.b_ones != 0, tid);
-  store_tile<BM, BK, LT>(ra, As, g.a_kc, g.a_op, g.kscale, g.k_per_scale, m0, g.M, kbeg, tid);
-  store_tile<BN, BK, LT>(rb, Bs, g.b_kc, g.b_op, nullptr, 1, n0, g.N, kbeg, tid);
+  Stager<AT, BM, BK, LT> ra;
+  Stager<BT, BN, BK, LT> rb;
+  ra.load(g.A, g.a_kc, g.lda, m0, g.M, kbeg, kend, false, tid);
+  rb.load(g.B, g.b_kc, g.ldb, n0, g.N, kbeg, kend, g.b_ones != 0, tid);
+  ra.store(As, g.a_kc, g.a_op, g.kscale, g.k_per_scale, m0, g.M, kbeg, tid);
+  rb.store(Bs, g.b_kc, g.b_op, nullptr, 1, n0, g.N, kbeg, tid);
   __syncthreads();
 
   int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
     if (more) {
-      load_tile<BM, BK>(ra, g.A, g.a_kc, g.lda, m0, g.M, k0 + BK, kend, false, tid);
-      load_tile<BN, BK>(rb, g.B, g.b_kc, g.ldb, n0, g.N, k0 + BK, kend, g.b_ones != 0, tid);
+      ra.load(g.A, g.a_kc, g.lda, m0, g.M, k0 + BK, kend, false, tid);
+      rb.load(g.B, g.b_kc, g.ldb, n0, g.N, k0 + BK, kend, g.b_ones != 0, tid);
     }
     TileMma<LT, TM, TN, BK>::run(acc, As + buf * BM * LD + ((wm * TM) * 32 + r) * LD,
                                  Bs + buf * BN * LD + ((wn * TN) * 32 + r) * LD, h);
     if (more) {
-      store_tile<BM, BK, LT>(ra, As + (buf ^ 1) * BM * LD, g.a_kc, g.a_op, g.kscale, g.k_per_scale, m0, g.M, k0 + BK, tid);
-      store_tile<BN, BK, LT>(rb, Bs + (buf ^ 1) * BN * LD, g.b_kc, g.b_op, nullptr, 1, n0, g.N, k0 + BK, tid);
+      ra.store(As + (buf ^ 1) * BM * LD, g.a_kc, g.a_op, g.kscale, g.k_per_scale, m0, g.M, k0 + BK, tid);
+      rb.store(Bs + (buf ^ 1) * BN * LD, g.b_kc, g.b_op, nullptr, 1, n0, g.N, k0 + BK, tid);
     }
     __syncthreads();
     buf ^= 1;
@@ -245,18 +392,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int kle
         v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
       }
       if (g.gaux) {
-        const float4 a = *reinterpret_cast<const float4*>(g.gaux + (int64_t)m * g.ldg + n);
+        float4 a;
+        if (g.gaux_bf16) {
+          const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(g.gaux) + (int64_t)m * g.ldg + n);
+          a = make_float4(bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y));
+        } else {
+          a = *reinterpret_cast<const float4*>(static_cast<const float*>(g.gaux) + (int64_t)m * g.ldg + n);
+        }
         v.x *= gelu_grad_f(a.x); v.y *= gelu_grad_f(a.y); v.z *= gelu_grad_f(a.z); v.w *= gelu_grad_f(a.w);
       }
       if (g.res) {
         const float4 a = *reinterpret_cast<const float4*>(g.res + (int64_t)m * g.ldr + n);
         v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
       }
-      float* dst = g.C + (int64_t)m * g.ldc + n;
-      if (g.atomic_out) {
-        atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+      if (g.c_bf16) {
+        *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(g.C) + (int64_t)m * g.ldc + n) =
+            make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
       } else {
-        *reinterpret_cast<float4*>(dst) = v;
+        float* dst = static_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
+        if (g.atomic_out) {
+          atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+        } else {
+          *reinterpret_cast<float4*>(dst) = v;
+        }
       }
     } else {
       const float e4[4] = {v.x, v.y, v.z, v.w};
@@ -267,10 +425,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int kle
         if (nn < g.N) {
           if (g.bias) val += g.bias[nn];
           if (g.rowscale) val *= g.rowscale[m / g.rows_per_scale];
-          if (g.gaux) val *= gelu_grad_f(g.gaux[(int64_t)m * g.ldg + nn]);
+          if (g.gaux) val *= gelu_grad_f(g.gaux_bf16 ? (float)reinterpret_cast<const __bf16*>(g.gaux)[(int64_t)m * g.ldg + nn]
+                                                     : static_cast<const float*>(g.gaux)[(int64_t)m * g.ldg + nn]);
           if (g.res) val += g.res[(int64_t)m * g.ldr + nn];
-          float* dst = g.C + (int64_t)m * g.ldc + nn;
-          if (g.atomic_out) atomicAdd(dst, val); else *dst = val;
+          if (g.c_bf16) {
+            reinterpret_cast<__bf16*>(g.C)[(int64_t)m * g.ldc + nn] = (__bf16)val;
+          } else {
+            float* dst = static_cast<float*>(g.C) + (int64_t)m * g.ldc + nn;
+            if (g.atomic_out) atomicAdd(dst, val); else *dst = val;
+          }
         } else if (g.b_ones && nn == g.N) {
           atomicAdd(g.C2 + m, val);
         }
@@ -305,7 +468,7 @@ Plan make_plan(const WmGemm& g, int ksplit) {
   return p;
 }
 
-template <typename LT, int WM, int WN, int TM, int TN, int BK>
+template <typename LT, typename AT, typename BT, int WM, int WN, int TM, int TN, int BK>
 int launch(const WmGemm& g, int ksplit, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int LD = BK + LdsT<LT>::PAD;
@@ -315,33 +478,33 @@ int launch(const WmGemm& g, int ksplit, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     if (smem > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<LT, WM, WN, TM, TN, BK>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<LT, AT, BT, WM, WN, TM, TN, BK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
   dim3 grid(p.tiles_n, p.tiles_m, p.ksplit);
-  const bool vec_ok = al16(g.C) && !(g.ldc & 3) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && !(g.ldr & 3))) &&
-                      (!g.gaux || (al16(g.gaux) && !(g.ldg & 3)));
-  hipLaunchKernelGGL((gemm_kernel<LT, WM, WN, TM, TN, BK>), grid, dim3(256), smem, st, g, p.klen, vec_ok);
+  const bool vec_ok = al16(g.C) && !(g.ldc & 7) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && !(g.ldr & 3))) &&
+                      (!g.gaux || (al16(g.gaux) && !(g.ldg & 7)));
+  hipLaunchKernelGGL((gemm_kernel<LT, AT, BT, WM, WN, TM, TN, BK>), grid, dim3(256), smem, st, g, p.klen, vec_ok);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
 
 // Tile choice: the largest tile whose grid still gives every CU at least ~1.5 workgroups; the transformer's
 // coarse stages (M = B*256 or B*64 tokens) otherwise leave most of the 256 CUs idle behind 128x128 tiles.
-template <typename LT, int BK>
+template <typename LT, typename AT, typename BT, int BK>
 int dispatch(const WmGemm& g, int ksplit, hipStream_t st) {
   const int ncols = g.N + (g.b_ones ? 1 : 0);
-  if (ncols <= 32) return launch<LT, 4, 1, 2, 1, BK>(g, ksplit, st);           // 256 x 32
+  if (ncols <= 32) return launch<LT, AT, BT, 4, 1, 2, 1, BK>(g, ksplit, st);           // 256 x 32
   const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((ncols + 127) / 128);
   const int64_t t12864 = (int64_t)((g.M + 127) / 128) * ((ncols + 63) / 64);
   const int64_t want = 384;
   // weight-gradient GEMMs get ~4x more workgroups from split-K; more splits than that cost more in fp32 atomics
   // (1.3 TB/s chip-wide) than the larger tile saves in operand re-reads (measured: 128x128 + deep split-K was slower)
   const int ks = g.atomic_out ? 4 : 1;
-  if (ncols > 64 && t128 * ks >= want) return launch<LT, 2, 2, 2, 2, BK>(g, ksplit, st);       // 128 x 128
-  if (t12864 * ks >= want || g.M >= 32768) return launch<LT, 2, 2, 2, 1, BK>(g, ksplit, st);   // 128 x 64
-  return launch<LT, 2, 2, 1, 1, BK>(g, ksplit, st);                            // 64 x 64
+  if (ncols > 64 && t128 * ks >= want) return launch<LT, AT, BT, 2, 2, 2, 2, BK>(g, ksplit, st);       // 128 x 128
+  if (t12864 * ks >= want || g.M >= 32768) return launch<LT, AT, BT, 2, 2, 2, 1, BK>(g, ksplit, st);   // 128 x 64
+  return launch<LT, AT, BT, 2, 2, 1, 1, BK>(g, ksplit, st);                            // 64 x 64
 }
 
 }  // namespace
@@ -352,18 +515,23 @@ extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
   if (!gp) return WM_EINVAL;
   const WmGemm& g = *gp;
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A || !g.B || !g.C) return WM_EINVAL;
-  if (!al16(g.A) || !al16(g.B) || (g.lda & 3) || (g.ldb & 3)) return WM_EINVAL;
-  if (g.a_kc && (g.K & 3)) return WM_EINVAL;
-  if (g.b_kc && (g.K & 3)) return WM_EINVAL;
+  const int amask = g.a_bf16 ? 7 : 3, bmask = g.b_bf16 ? 7 : 3;
+  if (!al16(g.A) || !al16(g.B) || (g.lda & amask) || (g.ldb & bmask)) return WM_EINVAL;
+  if (g.a_kc && (g.K & amask)) return WM_EINVAL;
+  if (g.b_kc && (g.K & bmask)) return WM_EINVAL;
   if (g.ksplit > 1 && !g.atomic_out) return WM_EINVAL;
+  if (g.atomic_out && g.c_bf16) return WM_EINVAL;
+  if (g.mode == 0 && (g.a_bf16 || g.b_bf16)) return WM_EINVAL;       // parity mode keeps fp32 storage end to end
   if (g.b_ones && !g.C2) return WM_EINVAL;
   if (g.kscale && (g.k_per_scale <= 0 || (g.k_per_scale & 3))) return WM_EINVAL;
   if (g.rowscale && g.rows_per_scale <= 0) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (g.mode == 0) return dispatch<float, 32>(g, g.ksplit, st);
+  if (g.mode == 0) return dispatch<float, float, float, 32>(g, g.ksplit, st);
   if (g.mode == 1) {
-    static const int bk = [] { const char* e = getenv("WM_GEMM_BK"); return e ? atoi(e) : 64; }();
-    return bk == 32 ? dispatch<__bf16, 32>(g, g.ksplit, st) : dispatch<__bf16, 64>(g, g.ksplit, st);
+    if (g.a_bf16 && g.b_bf16) return dispatch<__bf16, __bf16, __bf16, 64>(g, g.ksplit, st);
+    if (g.a_bf16) return dispatch<__bf16, __bf16, float, 64>(g, g.ksplit, st);
+    if (g.b_bf16) return dispatch<__bf16, float, __bf16, 64>(g, g.ksplit, st);
+    return dispatch<__bf16, float, float, 64>(g, g.ksplit, st);
   }
   return WM_EINVAL;
 }

@@ -7,7 +7,8 @@
 
 namespace {
 
-__global__ void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int hw, int C,
+template <typename OT>
+__global__ void im2col_kernel(const float* __restrict__ x, OT* __restrict__ cols, int B, int hw, int C,
                               int64_t total) {
   const int c4n = C / 4, oh = hw / 2;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -20,11 +21,12 @@ __global__ void im2col_kernel(const float* __restrict__ x, float* __restrict__ c
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (yy >= 0 && yy < hw && xx >= 0 && xx < hw)
       v = *reinterpret_cast<const float4*>(x + (((int64_t)b * hw + yy) * hw + xx) * C + 4 * c4);
-    *reinterpret_cast<float4*>(cols + (m * 16 + tap) * C + 4 * c4) = v;
+    IO<OT>::st4(cols + (m * 16 + tap) * C + 4 * c4, v);
   }
 }
 
-__global__ void col2im_kernel(const float* __restrict__ dcols, float* __restrict__ dx, int B, int hw, int C,
+template <typename IT>
+__global__ void col2im_kernel(const IT* __restrict__ dcols, float* __restrict__ dx, int B, int hw, int C,
                               int64_t total) {
   const int c4n = C / 4, oh = hw / 2;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -42,7 +44,7 @@ __global__ void col2im_kernel(const float* __restrict__ dcols, float* __restrict
         const int j = ((xx + 1) >> 1) - c, dj = xx + 1 - 2 * j;
         if (j < 0 || j >= oh || dj > 3) continue;
         const int64_t m = ((int64_t)b * oh + i) * oh + j;
-        const float4 v = *reinterpret_cast<const float4*>(dcols + (m * 16 + di * 4 + dj) * C + 4 * c4);
+        const float4 v = IO<IT>::ld4(dcols + (m * 16 + di * 4 + dj) * C + 4 * c4);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
     }
@@ -51,7 +53,8 @@ __global__ void col2im_kernel(const float* __restrict__ dcols, float* __restrict
 }
 
 // y4[m, t*Co + o] (+ bias[o]) -> dst[b, 2i+di, 2j+dj, c0+o]
-__global__ void shuffle_kernel(const float* __restrict__ y4, const float* __restrict__ bias, float* __restrict__ dst,
+template <typename IT>
+__global__ void shuffle_kernel(const IT* __restrict__ y4, const float* __restrict__ bias, float* __restrict__ dst,
                                int B, int hw, int Co, int64_t ldd, int c0, int64_t total) {
   const int o4n = Co / 4;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -60,7 +63,7 @@ __global__ void shuffle_kernel(const float* __restrict__ y4, const float* __rest
     const int t = (int)((idx / o4n) % 4);
     const int64_t m = idx / ((int64_t)o4n * 4);
     const int j = (int)(m % hw), i = (int)((m / hw) % hw), b = (int)(m / ((int64_t)hw * hw));
-    float4 v = *reinterpret_cast<const float4*>(y4 + (m * 4 + t) * Co + 4 * o4);
+    float4 v = IO<IT>::ld4(y4 + (m * 4 + t) * Co + 4 * o4);
     if (bias) {
       const float4 bb = *reinterpret_cast<const float4*>(bias + 4 * o4);
       v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
@@ -70,7 +73,8 @@ __global__ void shuffle_kernel(const float* __restrict__ y4, const float* __rest
   }
 }
 
-__global__ void unshuffle_kernel(const float* __restrict__ dsrc, float* __restrict__ dy4, int B, int hw, int Co,
+template <typename OT>
+__global__ void unshuffle_kernel(const float* __restrict__ dsrc, OT* __restrict__ dy4, int B, int hw, int Co,
                                  int64_t lds, int c0, int64_t total) {
   const int o4n = Co / 4;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -80,8 +84,7 @@ __global__ void unshuffle_kernel(const float* __restrict__ dsrc, float* __restri
     const int64_t m = idx / ((int64_t)o4n * 4);
     const int j = (int)(m % hw), i = (int)((m / hw) % hw), b = (int)(m / ((int64_t)hw * hw));
     const int64_t row = ((int64_t)b * 2 * hw + 2 * i + (t >> 1)) * 2 * hw + 2 * j + (t & 1);
-    *reinterpret_cast<float4*>(dy4 + (m * 4 + t) * Co + 4 * o4) =
-        *reinterpret_cast<const float4*>(dsrc + row * lds + c0 + 4 * o4);
+    IO<OT>::st4(dy4 + (m * 4 + t) * Co + 4 * o4, *reinterpret_cast<const float4*>(dsrc + row * lds + c0 + 4 * o4));
   }
 }
 
@@ -102,7 +105,8 @@ __global__ void copy_cols_kernel(const float* __restrict__ src, int64_t lds, int
   }
 }
 
-__global__ void strided3_kernel(const float* __restrict__ in, float* __restrict__ out, int n0, int n1, int n2,
+template <typename OT>
+__global__ void strided3_kernel(const float* __restrict__ in, OT* __restrict__ out, int n0, int n1, int n2,
                                 int64_t si0, int64_t si1, int64_t si2, int64_t so0, int64_t so1, int64_t so2,
                                 int atomic) {
   const int64_t total = (int64_t)n0 * n1 * n2;
@@ -110,8 +114,8 @@ __global__ void strided3_kernel(const float* __restrict__ in, float* __restrict_
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int i2 = (int)(idx % n2), i1 = (int)((idx / n2) % n1), i0 = (int)(idx / ((int64_t)n1 * n2));
     const float v = in[i0 * si0 + i1 * si1 + i2 * si2];
-    float* d = out + i0 * so0 + i1 * so1 + i2 * so2;
-    if (atomic) atomicAdd(d, v); else *d = v;
+    OT* d = out + i0 * so0 + i1 * so1 + i2 * so2;
+    if constexpr (sizeof(OT) == 4) { if (atomic) atomicAdd(d, v); else *d = v; } else { *d = (OT)v; }
   }
 }
 
@@ -119,6 +123,11 @@ __global__ void axpbyz_kernel(float* __restrict__ out, float a, const float* __r
                               const float* __restrict__ y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    IO<__bf16>::st4(dst + 4 * i, *reinterpret_cast<const float4*>(src + 4 * i));
 }
 
 // Payload feature [B,4,64] tiled (1,16,8) into the first 512 channels of the bottleneck concat
@@ -151,38 +160,60 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
-extern "C" int wm_im2col_4x4s2(const float* x, float* cols, int32_t B, int32_t hw, int32_t C, void* stream) {
+extern "C" int wm_im2col_4x4s2(const float* x, void* cols, int32_t cols_bf16, int32_t B, int32_t hw, int32_t C,
+                               void* stream) {
   if (!x || !cols || B <= 0 || hw < 2 || (hw & 1) || C < 4 || (C & 3)) return WM_EINVAL;
   const int64_t total = (int64_t)B * (hw / 2) * (hw / 2) * 16 * (C / 4);
-  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, cols,
-                     B, hw, C, total);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (cols_bf16)
+    hipLaunchKernelGGL(im2col_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, x, static_cast<__bf16*>(cols), B, hw,
+                       C, total);
+  else
+    hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, x, static_cast<float*>(cols), B, hw, C,
+                       total);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
-extern "C" int wm_col2im_4x4s2(const float* dcols, float* dx, int32_t B, int32_t hw, int32_t C, void* stream) {
+extern "C" int wm_col2im_4x4s2(const void* dcols, int32_t dcols_bf16, float* dx, int32_t B, int32_t hw, int32_t C,
+                               void* stream) {
   if (!dcols || !dx || B <= 0 || hw < 2 || (hw & 1) || C < 4 || (C & 3)) return WM_EINVAL;
   const int64_t total = (int64_t)B * hw * hw * (C / 4);
-  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), dcols, dx,
-                     B, hw, C, total);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dcols_bf16)
+    hipLaunchKernelGGL(col2im_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const __bf16*>(dcols), dx,
+                       B, hw, C, total);
+  else
+    hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const float*>(dcols), dx,
+                       B, hw, C, total);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
-extern "C" int wm_pixel_shuffle2(const float* y4, const float* bias, float* dst, int32_t B, int32_t hw, int32_t Co,
-                                 int64_t ldd, int32_t c0, void* stream) {
+extern "C" int wm_pixel_shuffle2(const void* y4, int32_t y4_bf16, const float* bias, float* dst, int32_t B, int32_t hw,
+                                 int32_t Co, int64_t ldd, int32_t c0, void* stream) {
   if (!y4 || !dst || B <= 0 || hw <= 0 || Co < 4 || (Co & 3) || (ldd & 3) || (c0 & 3) || !al16(dst)) return WM_EINVAL;
   const int64_t total = (int64_t)B * hw * hw * 4 * (Co / 4);
-  hipLaunchKernelGGL(shuffle_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), y4, bias,
-                     dst, B, hw, Co, ldd, c0, total);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (y4_bf16)
+    hipLaunchKernelGGL(shuffle_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const __bf16*>(y4), bias,
+                       dst, B, hw, Co, ldd, c0, total);
+  else
+    hipLaunchKernelGGL(shuffle_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const float*>(y4), bias,
+                       dst, B, hw, Co, ldd, c0, total);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
-extern "C" int wm_pixel_unshuffle2(const float* dsrc, float* dy4, int32_t B, int32_t hw, int32_t Co, int64_t lds,
-                                   int32_t c0, void* stream) {
+extern "C" int wm_pixel_unshuffle2(const float* dsrc, void* dy4, int32_t dy4_bf16, int32_t B, int32_t hw, int32_t Co,
+                                   int64_t lds, int32_t c0, void* stream) {
   if (!dsrc || !dy4 || B <= 0 || hw <= 0 || Co < 4 || (Co & 3) || (lds & 3) || (c0 & 3) || !al16(dsrc))
     return WM_EINVAL;
   const int64_t total = (int64_t)B * hw * hw * 4 * (Co / 4);
-  hipLaunchKernelGGL(unshuffle_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), dsrc,
-                     dy4, B, hw, Co, lds, c0, total);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dy4_bf16)
+    hipLaunchKernelGGL(unshuffle_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, dsrc, static_cast<__bf16*>(dy4), B,
+                       hw, Co, lds, c0, total);
+  else
+    hipLaunchKernelGGL(unshuffle_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, dsrc, static_cast<float*>(dy4), B,
+                       hw, Co, lds, c0, total);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
@@ -197,11 +228,16 @@ extern "C" int wm_copy_cols(const float* src, int64_t lds, int32_t s0, float* ds
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
-extern "C" int wm_strided3(const float* in, float* out, int32_t n0, int32_t n1, int32_t n2, int64_t si0, int64_t si1,
-                           int64_t si2, int64_t so0, int64_t so1, int64_t so2, int32_t atomic, void* stream) {
-  if (!in || !out || n0 <= 0 || n1 <= 0 || n2 <= 0) return WM_EINVAL;
-  hipLaunchKernelGGL(strided3_kernel, dim3(grid_for((int64_t)n0 * n1 * n2)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), in, out, n0, n1, n2, si0, si1, si2, so0, so1, so2, atomic);
+extern "C" int wm_strided3(const float* in, void* out, int32_t out_bf16, int32_t n0, int32_t n1, int32_t n2, int64_t si0,
+                           int64_t si1, int64_t si2, int64_t so0, int64_t so1, int64_t so2, int32_t atomic, void* stream) {
+  if (!in || !out || n0 <= 0 || n1 <= 0 || n2 <= 0 || (out_bf16 && atomic)) return WM_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (out_bf16)
+    hipLaunchKernelGGL(strided3_kernel<__bf16>, dim3(grid_for((int64_t)n0 * n1 * n2)), dim3(256), 0, st, in,
+                       static_cast<__bf16*>(out), n0, n1, n2, si0, si1, si2, so0, so1, so2, 0);
+  else
+    hipLaunchKernelGGL(strided3_kernel<float>, dim3(grid_for((int64_t)n0 * n1 * n2)), dim3(256), 0, st, in,
+                       static_cast<float*>(out), n0, n1, n2, si0, si1, si2, so0, so1, so2, atomic);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
@@ -209,6 +245,13 @@ extern "C" int wm_axpbyz(float* out, float a, const float* x, float b, const flo
   if (!out || !x || n <= 0) return WM_EINVAL;
   hipLaunchKernelGGL(axpbyz_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), out, a, x, b, y,
                      n);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst || n <= 0 || (n & 3) || !al16(src)) return WM_EINVAL;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                     static_cast<__bf16*>(dst), n / 4);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

@@ -23,10 +23,10 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-template <int C>
+template <int C, typename YT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const float* __restrict__ mod,
-                                                     float* __restrict__ y, float* __restrict__ mean,
+                                                     YT* __restrict__ y, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int64_t rows, int hw, int shift) {
   constexpr int L = (C / 4 < 64) ? C / 4 : 64;
   constexpr int V = C / (4 * L);
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       const float4 mm = *reinterpret_cast<const float4*>(mrow + c);
       o.x += mm.x; o.y += mm.y; o.z += mm.z; o.w += mm.w;
     }
-    *reinterpret_cast<float4*>(y + row * C + c) = o;
+    IO<YT>::st4(y + row * C + c, o);
   }
   if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
 }
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.
 // dgamma / dbeta: per-lane partial sums over the rows this wave visits, then LDS + atomics.
 constexpr int LNB_WAVES = 8;      // 512-thread blocks: 4x fewer same-address atomics per launch than 2048 x 256 threads
-template <int C>
-__global__ __launch_bounds__(512) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int C, typename DT>
+__global__ __launch_bounds__(512) void ln_bwd_kernel(const DT* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ dgamma,
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const float* __restrict__ d
     for (int q = 0; q < V; ++q) {
       const int c = (q * L + sub) * 4;
       const float4 xv = *reinterpret_cast<const float4*>(x + row * C + c);
-      const float4 dv = *reinterpret_cast<const float4*>(dy + row * C + c);
+      const float4 dv = IO<DT>::ld4(dy + row * C + c);
       xh[q] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
       g[q] = make_float4(dv.x * gm[q].x, dv.y * gm[q].y, dv.z * gm[q].z, dv.w * gm[q].w);
       s1 += (g[q].x + g[q].y) + (g[q].z + g[q].w);
@@ -153,7 +153,8 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // dmod[pos, c] += sum over windows of dy[token(window, pos), c]
-__global__ __launch_bounds__(256) void ln_dmod_kernel(const float* __restrict__ dy, float* __restrict__ dmod,
+template <typename DT>
+__global__ __launch_bounds__(256) void ln_dmod_kernel(const DT* __restrict__ dy, float* __restrict__ dmod,
                                                       int B, int hw, int C, int shift, int wchunk) {
   __shared__ float4 red[256];
   const int pos = blockIdx.x, py = pos >> 3, px = pos & 7;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void ln_dmod_kernel(const float* __restrict__ 
     const int b = w / (nw * nw), wr = w - b * nw * nw, wy = wr / nw, wx = wr - wy * nw;
     const int yy = (wy * 8 + py + shift) % hw, xx = (wx * 8 + px + shift) % hw;
     const int64_t row = (int64_t)b * hw * hw + yy * hw + xx;
-    const float4 v = *reinterpret_cast<const float4*>(dy + row * C + c4 * 4);
+    const float4 v = IO<DT>::ld4(dy + row * C + c4 * 4);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
   red[threadIdx.x] = acc;
@@ -182,25 +183,33 @@ __global__ __launch_bounds__(256) void ln_dmod_kernel(const float* __restrict__ 
 }
 
 template <int C>
-int ln_fwd_launch(const float* x, const float* g, const float* b, const float* mod, float* y, float* mean,
+int ln_fwd_launch(const float* x, const float* g, const float* b, const float* mod, void* y, int y_bf16, float* mean,
                   float* rstd, int64_t rows, int hw, int shift, hipStream_t st) {
   constexpr int L = (C / 4 < 64) ? C / 4 : 64;
   constexpr int RPB = 4 * (64 / L);
   const int64_t blocks = (rows + RPB - 1) / RPB;
-  hipLaunchKernelGGL((ln_fwd_kernel<C>), dim3((unsigned)blocks), dim3(256), 0, st, x, g, b, mod, y, mean, rstd,
-                     rows, hw, shift);
+  if (y_bf16)
+    hipLaunchKernelGGL((ln_fwd_kernel<C, __bf16>), dim3((unsigned)blocks), dim3(256), 0, st, x, g, b, mod,
+                       static_cast<__bf16*>(y), mean, rstd, rows, hw, shift);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<C, float>), dim3((unsigned)blocks), dim3(256), 0, st, x, g, b, mod,
+                       static_cast<float*>(y), mean, rstd, rows, hw, shift);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
 template <int C>
-int ln_bwd_launch(const float* dy, const float* x, const float* g, const float* mean, const float* rstd,
+int ln_bwd_launch(const void* dy, int dy_bf16, const float* x, const float* g, const float* mean, const float* rstd,
                   const float* dres, float* dx, float* dg, float* db, int64_t rows, hipStream_t st) {
   constexpr int L = (C / 4 < 64) ? C / 4 : 64;
   constexpr int RPB = LNB_WAVES * (64 / L);
   int64_t blocks = (rows + RPB - 1) / RPB;
   if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL((ln_bwd_kernel<C>), dim3((unsigned)blocks), dim3(512), 0, st, dy, x, g, mean, rstd, dres,
-                     dx, dg, db, rows);
+  if (dy_bf16)
+    hipLaunchKernelGGL((ln_bwd_kernel<C, __bf16>), dim3((unsigned)blocks), dim3(512), 0, st,
+                       static_cast<const __bf16*>(dy), x, g, mean, rstd, dres, dx, dg, db, rows);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<C, float>), dim3((unsigned)blocks), dim3(512), 0, st,
+                       static_cast<const float*>(dy), x, g, mean, rstd, dres, dx, dg, db, rows);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
@@ -208,22 +217,22 @@ int ln_bwd_launch(const float* dy, const float* x, const float* g, const float* 
 }  // namespace
 
 extern "C" int wm_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* modulator,
-                                float* y, float* mean, float* rstd, int64_t rows, int32_t C, int32_t hw,
-                                int32_t shift, void* stream) {
+                                void* y, int32_t y_bf16, float* mean, float* rstd, int64_t rows, int32_t C,
+                                int32_t hw, int32_t shift, void* stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return WM_EINVAL;
   if (modulator && (hw <= 0 || (hw & 7) || rows % ((int64_t)hw * hw))) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (C) {
-    case 32: return ln_fwd_launch<32>(x, gamma, beta, modulator, y, mean, rstd, rows, hw, shift, st);
-    case 64: return ln_fwd_launch<64>(x, gamma, beta, modulator, y, mean, rstd, rows, hw, shift, st);
-    case 128: return ln_fwd_launch<128>(x, gamma, beta, modulator, y, mean, rstd, rows, hw, shift, st);
-    case 256: return ln_fwd_launch<256>(x, gamma, beta, modulator, y, mean, rstd, rows, hw, shift, st);
-    case 512: return ln_fwd_launch<512>(x, gamma, beta, modulator, y, mean, rstd, rows, hw, shift, st);
+    case 32: return ln_fwd_launch<32>(x, gamma, beta, modulator, y, y_bf16, mean, rstd, rows, hw, shift, st);
+    case 64: return ln_fwd_launch<64>(x, gamma, beta, modulator, y, y_bf16, mean, rstd, rows, hw, shift, st);
+    case 128: return ln_fwd_launch<128>(x, gamma, beta, modulator, y, y_bf16, mean, rstd, rows, hw, shift, st);
+    case 256: return ln_fwd_launch<256>(x, gamma, beta, modulator, y, y_bf16, mean, rstd, rows, hw, shift, st);
+    case 512: return ln_fwd_launch<512>(x, gamma, beta, modulator, y, y_bf16, mean, rstd, rows, hw, shift, st);
     default: return WM_EINVAL;
   }
 }
 
-extern "C" int wm_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+extern "C" int wm_layernorm_bwd(const void* dy, int32_t dy_bf16, const float* x, const float* gamma, const float* mean,
                                 const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                                 float* dmod, int64_t rows, int32_t C, int32_t hw, int32_t shift, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return WM_EINVAL;
@@ -231,11 +240,11 @@ extern "C" int wm_layernorm_bwd(const float* dy, const float* x, const float* ga
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
   switch (C) {
-    case 32: rc = ln_bwd_launch<32>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
-    case 64: rc = ln_bwd_launch<64>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
-    case 128: rc = ln_bwd_launch<128>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
-    case 256: rc = ln_bwd_launch<256>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
-    case 512: rc = ln_bwd_launch<512>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
+    case 32: rc = ln_bwd_launch<32>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
+    case 64: rc = ln_bwd_launch<64>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
+    case 128: rc = ln_bwd_launch<128>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
+    case 256: rc = ln_bwd_launch<256>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
+    case 512: rc = ln_bwd_launch<512>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
     default: return WM_EINVAL;
   }
   if (rc) return rc;
@@ -245,7 +254,12 @@ extern "C" int wm_layernorm_bwd(const float* dy, const float* x, const float* ga
     int chunks = (nwin + 63) / 64;
     if (chunks > 32) chunks = 32;
     const int wchunk = (nwin + chunks - 1) / chunks;
-    hipLaunchKernelGGL(ln_dmod_kernel, dim3(64, chunks), dim3(256), 0, st, dy, dmod, B, hw, C, shift, wchunk);
+    if (dy_bf16)
+      hipLaunchKernelGGL(ln_dmod_kernel<__bf16>, dim3(64, chunks), dim3(256), 0, st, static_cast<const __bf16*>(dy), dmod,
+                         B, hw, C, shift, wchunk);
+    else
+      hipLaunchKernelGGL(ln_dmod_kernel<float>, dim3(64, chunks), dim3(256), 0, st, static_cast<const float*>(dy), dmod,
+                         B, hw, C, shift, wchunk);
     WM_CHECK_LAUNCH();
   }
   return WM_OK;

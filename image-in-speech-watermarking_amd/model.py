@@ -226,6 +226,7 @@ class UformerAudio(nn.Module):
         pad = (-total) % 64
         self._flat = torch.zeros(total + pad, device=device, dtype=torch.float32) if flat is None else flat
         self._flat_grad = torch.zeros(total + pad, device=device, dtype=torch.float32)
+        self._flat_h = None                               # bf16 copy of the arena (GEMM B operands in bf16 mode)
         self._views, self._gviews = {}, {}
         for name, shape, kind in self._specs:
             n, off = math.prod(shape), self._offsets[name]
@@ -279,6 +280,27 @@ class UformerAudio(nn.Module):
     def _mode(self):
         return {"fp32": ops.MODE_FP32, "bf16": ops.MODE_BF16}[self.compute_mode]
 
+    # bf16 mode stores the WIDE activations (LN outputs, qkv, attention output, LeFF hidden tensors, im2col buffers and
+    # their gradients) and a copy of the weights in bf16; the residual stream, parameters, gradients and LN statistics
+    # stay fp32.  fp32 ("parity") mode keeps everything fp32.
+    def _H(self, dev, *shape):
+        return torch.empty(shape, device=dev, dtype=torch.bfloat16 if self.compute_mode == "bf16" else torch.float32)
+
+    def _refresh_weight_copy(self):
+        if self.compute_mode != "bf16":
+            return
+        if self._flat_h is None or self._flat_h.device != self._flat.device:
+            self._flat_h = torch.empty(self._flat.numel(), device=self._flat.device, dtype=torch.bfloat16)
+        ops.cast_bf16(self._flat, self._flat_h, self._flat.numel())
+
+    def _W(self, name):
+        """GEMM weight operand: fp32 parameter view, or its bf16 copy in bf16 mode."""
+        v = self._views[name]
+        if self.compute_mode != "bf16":
+            return v
+        off = (v.data_ptr() - self._flat.data_ptr()) // 4
+        return self._flat_h[off:off + v.numel()].view(v.shape)
+
     def _ensure_runtime(self, device):
         if self._anchor is None or self._anchor.device != device:
             self._anchor = torch.zeros(1, device=device, requires_grad=True)
@@ -301,6 +323,7 @@ class UformerAudio(nn.Module):
         self._ensure_runtime(y.device)
         with torch.no_grad():
             B = y.shape[0]
+            self._refresh_weight_copy()
             feat, _ = self._trunk_fwd("decoder_wm.", y.contiguous().float(), B, None, 0, extractor=True)
             return self._ae_decode_fwd(feat, B)[0]
 
@@ -337,23 +360,24 @@ class UformerAudio(nn.Module):
     def _block_fwd(self, pre, x, B, C, hw, shift, s1, s2, mod):
         P, dev, mode = self._views, x.device, self._mode()
         M, N = x.shape[0], hw * hw
-        xn1, mean1, rstd1 = _E(dev, M, C), _E(dev, M), _E(dev, M)
+        H, W = self._H, self._W
+        xn1, mean1, rstd1 = H(dev, M, C), _E(dev, M), _E(dev, M)
         ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], P[pre + "modulator.weight"] if mod else None,
                           xn1, mean1, rstd1, hw, shift)
-        qkv = _E(dev, M, 3 * C)
-        ops.linear_fwd(xn1, P[pre + "attn.qkv.w"], P[pre + "attn.qkv.b"], qkv, mode)
-        o = _E(dev, M, C)
+        qkv = H(dev, M, 3 * C)
+        ops.linear_fwd(xn1, W(pre + "attn.qkv.w"), P[pre + "attn.qkv.b"], qkv, mode)
+        o = H(dev, M, C)
         ops.winattn_fwd(qkv, P[pre + "attn.relative_position_bias_table"], o, B, hw, C, shift, mode)
         x1 = _E(dev, M, C)
-        ops.linear_fwd(o, P[pre + "attn.proj.weight"], P[pre + "attn.proj.bias"], x1, mode, res=x, rowscale=s1, rows_per_scale=N)
-        xn2, mean2, rstd2 = _E(dev, M, C), _E(dev, M), _E(dev, M)
+        ops.linear_fwd(o, W(pre + "attn.proj.weight"), P[pre + "attn.proj.bias"], x1, mode, res=x, rowscale=s1, rows_per_scale=N)
+        xn2, mean2, rstd2 = H(dev, M, C), _E(dev, M), _E(dev, M)
         ops.layernorm_fwd(x1, P[pre + "norm2.weight"], P[pre + "norm2.bias"], None, xn2, mean2, rstd2, hw, 0)
-        h1 = _E(dev, M, 4 * C)
-        ops.linear_fwd(xn2, P[pre + "mlp.linear1.0.weight"], P[pre + "mlp.linear1.0.bias"], h1, mode)
-        h2 = _E(dev, M, 4 * C)
+        h1 = H(dev, M, 4 * C)
+        ops.linear_fwd(xn2, W(pre + "mlp.linear1.0.weight"), P[pre + "mlp.linear1.0.bias"], h1, mode)
+        h2 = H(dev, M, 4 * C)
         ops.dwconv_fwd(h1, P[pre + "mlp.dwconv.0.weight"], P[pre + "mlp.dwconv.0.bias"], h2, B, hw, 4 * C)
         x2 = _E(dev, M, C)
-        ops.linear_fwd(h2, P[pre + "mlp.linear2.0.weight"], P[pre + "mlp.linear2.0.bias"], x2, mode, a_op=1, res=x1,
+        ops.linear_fwd(h2, W(pre + "mlp.linear2.0.weight"), P[pre + "mlp.linear2.0.bias"], x2, mode, a_op=1, res=x1,
                        rowscale=s2, rows_per_scale=N)
         return x2, (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2)
 
@@ -362,28 +386,29 @@ class UformerAudio(nn.Module):
         P, G, dev, mode = self._views, self._gviews, x.device, self._mode()
         M, N = x.shape[0], hw * hw
         # LeFF
-        dh2 = _E(dev, M, 4 * C)
-        ops.linear_bwd_input(dy, P[pre + "mlp.linear2.0.weight"], dh2, mode, rowscale=s2, rows_per_scale=N, gaux=h2)
+        H, W = self._H, self._W
+        dh2 = H(dev, M, 4 * C)
+        ops.linear_bwd_input(dy, W(pre + "mlp.linear2.0.weight"), dh2, mode, rowscale=s2, rows_per_scale=N, gaux=h2)
         ops.linear_bwd_weight(dy, h2, G[pre + "mlp.linear2.0.weight"], G[pre + "mlp.linear2.0.bias"], mode, x_op=1,
                               kscale=s2, k_per_scale=N)
-        dh1 = _E(dev, M, 4 * C)
+        dh1 = H(dev, M, 4 * C)
         ops.dwconv_bwd(h1, dh2, P[pre + "mlp.dwconv.0.weight"], dh1, G[pre + "mlp.dwconv.0.weight"],
                        G[pre + "mlp.dwconv.0.bias"], B, hw, 4 * C)
-        dxn2 = _E(dev, M, C)
-        ops.linear_bwd_input(dh1, P[pre + "mlp.linear1.0.weight"], dxn2, mode)
+        dxn2 = H(dev, M, C)
+        ops.linear_bwd_input(dh1, W(pre + "mlp.linear1.0.weight"), dxn2, mode)
         ops.linear_bwd_weight(dh1, xn2, G[pre + "mlp.linear1.0.weight"], G[pre + "mlp.linear1.0.bias"], mode)
         dx1 = _E(dev, M, C)
         ops.layernorm_bwd(dxn2, x1, P[pre + "norm2.weight"], mean2, rstd2, dy, dx1, G[pre + "norm2.weight"],
                           G[pre + "norm2.bias"], None, hw, 0)
         # attention
         do = dxn2                                                  # reuse buffer
-        ops.linear_bwd_input(dx1, P[pre + "attn.proj.weight"], do, mode, rowscale=s1, rows_per_scale=N)
+        ops.linear_bwd_input(dx1, W(pre + "attn.proj.weight"), do, mode, rowscale=s1, rows_per_scale=N)
         ops.linear_bwd_weight(dx1, o, G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], mode, kscale=s1, k_per_scale=N)
-        dqkv = _E(dev, M, 3 * C)
+        dqkv = H(dev, M, 3 * C)
         ops.winattn_bwd(qkv, P[pre + "attn.relative_position_bias_table"], do, dqkv,
                         G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, mode)
-        dxn1 = _E(dev, M, C)
-        ops.linear_bwd_input(dqkv, P[pre + "attn.qkv.w"], dxn1, mode)
+        dxn1 = H(dev, M, C)
+        ops.linear_bwd_input(dqkv, W(pre + "attn.qkv.w"), dxn1, mode)
         ops.linear_bwd_weight(dqkv, xn1, G[pre + "attn.qkv.w"], G[pre + "attn.qkv.b"], mode)
         dx = _E(dev, M, C)
         ops.layernorm_bwd(dxn1, x, P[pre + "norm1.weight"], mean1, rstd1, dx1, dx, G[pre + "norm1.weight"],
@@ -393,9 +418,9 @@ class UformerAudio(nn.Module):
     def _down_fwd(self, pre, x, B, hw, C):
         P, dev, mode = self._views, x.device, self._mode()
         Mo = B * (hw // 2) ** 2
-        cols = _E(dev, Mo, 16 * C)
+        cols = self._H(dev, Mo, 16 * C)
         ops.im2col(x, cols, B, hw, C)
-        w2 = _E(dev, 2 * C, 16 * C)
+        w2 = self._H(dev, 2 * C, 16 * C)
         ops.strided3(P[pre + "weight"], w2, (2 * C, 16, C), (16 * C, 1, 16), (16 * C, C, 1))
         y = _E(dev, Mo, 2 * C)
         ops.linear_fwd(cols, w2, P[pre + "bias"], y, mode)
@@ -405,7 +430,7 @@ class UformerAudio(nn.Module):
         pre, x, B, hw, C, w2 = sv
         G, dev, mode = self._gviews, x.device, self._mode()
         Mo = dy.shape[0]
-        dcols = _E(dev, Mo, 16 * C)
+        dcols = self._H(dev, Mo, 16 * C)
         ops.linear_bwd_input(dy, w2, dcols, mode)
         dx = _E(dev, x.shape[0], C)
         ops.col2im(dcols, dx, B, hw, C)
@@ -420,9 +445,9 @@ class UformerAudio(nn.Module):
         """x [B*hw*hw, Cin] -> concat([convT(x), skip]) [B*4hw*hw, 2Co]"""
         P, dev, mode = self._views, x.device, self._mode()
         M = x.shape[0]
-        wr = _E(dev, 4 * Co, Cin)
+        wr = self._H(dev, 4 * Co, Cin)
         ops.strided3(P[pre + "weight"], wr, (4, Co, Cin), (1, 4, 4 * Co), (Co * Cin, Cin, 1))
-        y4 = _E(dev, M, 4 * Co)
+        y4 = self._H(dev, M, 4 * Co)
         ops.linear_fwd(x, wr, None, y4, mode)
         cat = _E(dev, 4 * M, 2 * Co)
         ops.pixel_shuffle(y4, P[pre + "bias"], cat, B, hw, Co, 2 * Co, 0)
@@ -435,7 +460,7 @@ class UformerAudio(nn.Module):
         M = x.shape[0]
         dskip = _E(dev, 4 * M, Co)
         ops.copy_cols(dcat, 2 * Co, Co, dskip, Co, 0, 4 * M, Co)
-        dy4 = _E(dev, M, 4 * Co)
+        dy4 = self._H(dev, M, 4 * Co)
         ops.pixel_unshuffle(dcat, dy4, B, hw, Co, 2 * Co, 0)
         dx = _E(dev, M, Cin)
         ops.linear_bwd_input(dy4, wr, dx, mode)
@@ -560,6 +585,7 @@ class UformerAudio(nn.Module):
         if tuple(x.shape[1:]) != (2, 128, 128) or tuple(msg.shape) != (B, 1, 32, 32):
             raise ValueError("expected x [B,2,128,128] and message [B,1,32,32] (reference model.py:2384-2389)")
         scales = self._scales_for(B, train, keep_scales, dev)
+        self._refresh_weight_copy()
         n_trunk = 2 * len(self.arch.trunk_blocks())
         n_dec = 2 * len(self.arch.dec_blocks())
         S = {}

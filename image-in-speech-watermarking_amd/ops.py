@@ -17,10 +17,15 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _chk(*ts):
-    for t in ts:
-        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
-            raise ValueError("libwm_hip ops need contiguous float32 tensors")
+def _bf(t):
+    """1 if the tensor is stored as bf16 (wide activations / weight copies in bf16 mode), else 0 (fp32)."""
+    if t is None:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    if t.dtype != torch.float32:
+        raise ValueError(f"libwm_hip ops take float32 or bfloat16 tensors, got {t.dtype}")
+    return 0
 
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=1, b_kc=1, a_op=0, b_op=0, bias=None, res=None, ldr=0,
@@ -28,7 +33,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=1, b_kc=1, a_op=0, b_op=0, bia
          atomic_out=False, ksplit=0, mode=MODE_FP32):
     g = WmGemm(ptr(A), ptr(B), ptr(Cout), M, N, K, lda, ldb, ldc, a_kc, b_kc, a_op, b_op, ptr(bias), ptr(res), ldr,
                ptr(rowscale), rows_per_scale, ptr(kscale), k_per_scale, ptr(gaux), ldg, int(b_ones), ptr(C2),
-               int(atomic_out), ksplit, mode)
+               int(atomic_out), ksplit, mode, _bf(A), _bf(B), _bf(Cout), _bf(gaux))
     check(lib.wm_gemm(C.byref(g), _stream()), f"wm_gemm(M={M},N={N},K={K})")
 
 
@@ -58,48 +63,56 @@ def linear_bwd_weight(dy, x, dw, db, mode, x_op=0, kscale=None, k_per_scale=0):
 
 def layernorm_fwd(x, gamma, beta, mod, y, mean, rstd, hw, shift):
     rows, Cc = x.shape
-    check(lib.wm_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(mod), ptr(y), ptr(mean), ptr(rstd), rows, Cc, hw,
-                               shift, _stream()), "wm_layernorm_fwd")
+    check(lib.wm_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(mod), ptr(y), _bf(y), ptr(mean), ptr(rstd), rows, Cc,
+                               hw, shift, _stream()), "wm_layernorm_fwd")
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dmod, hw, shift):
     rows, Cc = x.shape
-    check(lib.wm_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dgamma),
-                               ptr(dbeta), ptr(dmod), rows, Cc, hw, shift, _stream()), "wm_layernorm_bwd")
+    check(lib.wm_layernorm_bwd(ptr(dy), _bf(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+                               ptr(dgamma), ptr(dbeta), ptr(dmod), rows, Cc, hw, shift, _stream()), "wm_layernorm_bwd")
 
 
 def winattn_fwd(qkv, table, out, B, hw, Cc, shift, mode):
-    check(lib.wm_winattn_fwd(ptr(qkv), ptr(table), ptr(out), B, hw, Cc, shift, mode, _stream()), "wm_winattn_fwd")
+    if _bf(qkv) != _bf(out):
+        raise ValueError("winattn: qkv and out must share a storage type")
+    check(lib.wm_winattn_fwd(ptr(qkv), ptr(table), ptr(out), _bf(qkv), B, hw, Cc, shift, mode, _stream()), "wm_winattn_fwd")
 
 
 def winattn_bwd(qkv, table, dout, dqkv, dtable, B, hw, Cc, shift, mode):
-    check(lib.wm_winattn_bwd(ptr(qkv), ptr(table), ptr(dout), ptr(dqkv), ptr(dtable), B, hw, Cc, shift, mode,
+    if not (_bf(qkv) == _bf(dout) == _bf(dqkv)):
+        raise ValueError("winattn_bwd: qkv, dout and dqkv must share a storage type")
+    check(lib.wm_winattn_bwd(ptr(qkv), ptr(table), ptr(dout), ptr(dqkv), ptr(dtable), _bf(qkv), B, hw, Cc, shift, mode,
                              _stream()), "wm_winattn_bwd")
 
 
 def dwconv_fwd(h1, w, b, h2, B, hw, Ch):
-    check(lib.wm_dwconv_fwd(ptr(h1), ptr(w), ptr(b), ptr(h2), B, hw, Ch, _stream()), "wm_dwconv_fwd")
+    if _bf(h1) != _bf(h2):
+        raise ValueError("dwconv: h1 and h2 must share a storage type")
+    check(lib.wm_dwconv_fwd(ptr(h1), ptr(w), ptr(b), ptr(h2), _bf(h1), B, hw, Ch, _stream()), "wm_dwconv_fwd")
 
 
 def dwconv_bwd(h1, dh2, w, dh1, dw, db, B, hw, Ch):
-    check(lib.wm_dwconv_bwd(ptr(h1), ptr(dh2), ptr(w), ptr(dh1), ptr(dw), ptr(db), B, hw, Ch, _stream()),
+    if not (_bf(h1) == _bf(dh2) == _bf(dh1)):
+        raise ValueError("dwconv_bwd: h1, dh2 and dh1 must share a storage type")
+    check(lib.wm_dwconv_bwd(ptr(h1), ptr(dh2), ptr(w), ptr(dh1), ptr(dw), ptr(db), _bf(h1), B, hw, Ch, _stream()),
           "wm_dwconv_bwd")
 
 
 def im2col(x, cols, B, hw, Cc):
-    check(lib.wm_im2col_4x4s2(ptr(x), ptr(cols), B, hw, Cc, _stream()), "wm_im2col_4x4s2")
+    check(lib.wm_im2col_4x4s2(ptr(x), ptr(cols), _bf(cols), B, hw, Cc, _stream()), "wm_im2col_4x4s2")
 
 
 def col2im(dcols, dx, B, hw, Cc):
-    check(lib.wm_col2im_4x4s2(ptr(dcols), ptr(dx), B, hw, Cc, _stream()), "wm_col2im_4x4s2")
+    check(lib.wm_col2im_4x4s2(ptr(dcols), _bf(dcols), ptr(dx), B, hw, Cc, _stream()), "wm_col2im_4x4s2")
 
 
 def pixel_shuffle(y4, bias, dst, B, hw, Co, ldd, c0):
-    check(lib.wm_pixel_shuffle2(ptr(y4), ptr(bias), ptr(dst), B, hw, Co, ldd, c0, _stream()), "wm_pixel_shuffle2")
+    check(lib.wm_pixel_shuffle2(ptr(y4), _bf(y4), ptr(bias), ptr(dst), B, hw, Co, ldd, c0, _stream()), "wm_pixel_shuffle2")
 
 
 def pixel_unshuffle(dsrc, dy4, B, hw, Co, lds, c0):
-    check(lib.wm_pixel_unshuffle2(ptr(dsrc), ptr(dy4), B, hw, Co, lds, c0, _stream()), "wm_pixel_unshuffle2")
+    check(lib.wm_pixel_unshuffle2(ptr(dsrc), ptr(dy4), _bf(dy4), B, hw, Co, lds, c0, _stream()), "wm_pixel_unshuffle2")
 
 
 def copy_cols(src, lds, s0, dst, ldd, c0, rows, Cc, accumulate=False):
@@ -107,8 +120,12 @@ def copy_cols(src, lds, s0, dst, ldd, c0, rows, Cc, accumulate=False):
 
 
 def strided3(src, dst, n, si, so, atomic=False):
-    check(lib.wm_strided3(ptr(src), ptr(dst), n[0], n[1], n[2], si[0], si[1], si[2], so[0], so[1], so[2], int(atomic),
-                          _stream()), "wm_strided3")
+    check(lib.wm_strided3(ptr(src), ptr(dst), _bf(dst), n[0], n[1], n[2], si[0], si[1], si[2], so[0], so[1], so[2],
+                          int(atomic), _stream()), "wm_strided3")
+
+
+def cast_bf16(src, dst, n):
+    check(lib.wm_cast_bf16(ptr(src), ptr(dst), n, _stream()), "wm_cast_bf16")
 
 
 def msg_expand_fwd(feat, dst, B):

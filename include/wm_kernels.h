@@ -3,7 +3,9 @@
  * The reference has no native/FFI surface: its hot path is PyTorch ATen calls inside
  * uformerWM/model.py.  Each entry point below replaces the ATen op group named in its comment
  * (file:line in /root/reference).  Conventions:
- *   - every pointer is DEVICE memory (fp32 unless stated), owned by the caller, never retained;
+ *   - every pointer is DEVICE memory (fp32 unless stated), owned by the caller, never retained; `void*` tensor
+ *     arguments carry fp32 or bf16 according to the `*_bf16` flag next to them (bf16 = the wide activations of
+ *     mode 1; the residual stream, parameters, gradients and statistics are always fp32);
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it, no host sync,
  *     no allocation (hipGraph-capturable);
  *   - return 0 on success, WM_EINVAL (22) for a shape/alignment the kernel does not support,
@@ -30,7 +32,7 @@ int wm_abi_version(void);
  * Downsample/Upsample as im2col GEMMs (:763,789) and their autograd backward.
  */
 typedef struct WmGemm {
-  const float* A; const float* B; float* C;
+  const void* A; const void* B; void* C;    /* fp32, or bf16 where the *_bf16 flag below is set (mode 1 only)      */
   int32_t M, N, K;
   int64_t lda, ldb, ldc;     /* lda: row stride if a_kc else k stride (elements); same for ldb */
   int32_t a_kc, b_kc;        /* 1: operand is K-contiguous, 0: row-contiguous                   */
@@ -39,55 +41,58 @@ typedef struct WmGemm {
   const float* res; int64_t ldr;              /* residual [M,N] or NULL                        */
   const float* rowscale; int32_t rows_per_scale; /* per-sample DropPath scale or NULL           */
   const float* kscale; int32_t k_per_scale;   /* scale on A along K (weight-grad GEMMs) or NULL */
-  const float* gaux; int64_t ldg;             /* multiply by gelu'(gaux[m,n]) or NULL           */
+  const void* gaux; int64_t ldg;              /* multiply by gelu'(gaux[m,n]) or NULL           */
   int32_t b_ones;            /* B has a virtual row n==N of ones; that column is added to C2[m] */
   float* C2;
   int32_t atomic_out;        /* 1: atomicAdd into C (gradient accumulation, split-K)            */
   int32_t ksplit;            /* >=1 number of K splits (needs atomic_out when >1); 0 = auto     */
   int32_t mode;
+  int32_t a_bf16, b_bf16, c_bf16, gaux_bf16; /* storage type of A / B / C / gaux: 0 fp32, 1 bf16 (bf16 C: no atomics)   */
 } WmGemm;
 int wm_gemm(const WmGemm* g, void* stream);
 
 /* ---- LayerNorm (+ window modulator) — model.py:982,1017 (norm1/norm2), :996-997 (modulator) ---- */
 int wm_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* modulator,
-                     float* y, float* mean, float* rstd, int64_t rows, int32_t C, int32_t hw,
+                     void* y, int32_t y_bf16, float* mean, float* rstd, int64_t rows, int32_t C, int32_t hw,
                      int32_t shift, void* stream);
 /* dx = dres + LN'(dy); dgamma/dbeta atomically accumulated; dmod[64,C] accumulated if not NULL */
-int wm_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+int wm_layernorm_bwd(const void* dy, int32_t dy_bf16, const float* x, const float* gamma, const float* mean,
                      const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                      float* dmod, int64_t rows, int32_t C, int32_t hw, int32_t shift, void* stream);
 
 /* ---- 8x8 window attention — model.py:523-551 with roll/partition/reverse (:987-1013) and the
  * shift mask (:954-972) folded into the indexing.  qkv: [B*hw*hw, 3C] (q|k|v), heads of 32.    */
-int wm_winattn_fwd(const float* qkv, const float* bias_table, float* out, int32_t B, int32_t hw,
+int wm_winattn_fwd(const void* qkv, const float* bias_table, void* out, int32_t io_bf16, int32_t B, int32_t hw,
                    int32_t C, int32_t shift, int32_t mode, void* stream);
-int wm_winattn_bwd(const float* qkv, const float* bias_table, const float* dout, float* dqkv,
-                   float* dbias_table, int32_t B, int32_t hw, int32_t C, int32_t shift,
+int wm_winattn_bwd(const void* qkv, const float* bias_table, const void* dout, void* dqkv,
+                   float* dbias_table, int32_t io_bf16, int32_t B, int32_t hw, int32_t C, int32_t shift,
                    int32_t mode, void* stream);
 
 /* ---- LeFF depthwise 3x3 on token-major [B,hw,hw,Ch] — model.py:703-709.  Input is the
  * PRE-GELU linear1 output; GELU is applied while staging.  Output is pre-GELU too.            */
-int wm_dwconv_fwd(const float* h1, const float* w, const float* b, float* h2, int32_t B, int32_t hw,
+int wm_dwconv_fwd(const void* h1, const float* w, const float* b, void* h2, int32_t io_bf16, int32_t B, int32_t hw,
                   int32_t Ch, void* stream);
 /* dh1 = gelu'(h1) * conv^T(dh2);  dw[Ch,9], db[Ch] accumulated */
-int wm_dwconv_bwd(const float* h1, const float* dh2, const float* w, float* dh1, float* dw, float* db,
-                  int32_t B, int32_t hw, int32_t Ch, void* stream);
+int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, void* dh1, float* dw, float* db,
+                  int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream);
 
 /* ---- data movement for Downsample (conv4x4 s2 p1, model.py:763) / Upsample (convT2x2 s2, :789) */
-int wm_im2col_4x4s2(const float* x, float* cols, int32_t B, int32_t hw, int32_t C, void* stream);
-int wm_col2im_4x4s2(const float* dcols, float* dx, int32_t B, int32_t hw, int32_t C, void* stream);
+int wm_im2col_4x4s2(const float* x, void* cols, int32_t cols_bf16, int32_t B, int32_t hw, int32_t C, void* stream);
+int wm_col2im_4x4s2(const void* dcols, int32_t dcols_bf16, float* dx, int32_t B, int32_t hw, int32_t C, void* stream);
 /* y4: [B*hw*hw, 4*Co] columns ordered (di,dj,o)  <->  dst[B,(2hw)^2, ldd] channels [c0, c0+Co) */
-int wm_pixel_shuffle2(const float* y4, const float* bias /* [Co] or NULL */, float* dst, int32_t B, int32_t hw,
-                      int32_t Co, int64_t ldd, int32_t c0, void* stream);
-int wm_pixel_unshuffle2(const float* dsrc, float* dy4, int32_t B, int32_t hw, int32_t Co, int64_t lds,
+int wm_pixel_shuffle2(const void* y4, int32_t y4_bf16, const float* bias /* [Co] or NULL */, float* dst, int32_t B,
+                      int32_t hw, int32_t Co, int64_t ldd, int32_t c0, void* stream);
+int wm_pixel_unshuffle2(const float* dsrc, void* dy4, int32_t dy4_bf16, int32_t B, int32_t hw, int32_t Co, int64_t lds,
                         int32_t c0, void* stream);
 /* dst[r, c0:c0+C] = src[r, s0:s0+C] (skip concat, model.py:1225; and its backward slice)      */
 int wm_copy_cols(const float* src, int64_t lds, int32_t s0, float* dst, int64_t ldd, int32_t c0,
                  int64_t rows, int32_t C, int32_t accumulate, void* stream);
 /* out[i0*so0+i1*so1+i2*so2] (=|atomic +=) in[i0*si0+i1*si1+i2*si2]: weight re-layouts for the conv GEMMs
  * ([o][c][tap] <-> [o][tap][c], ConvTranspose [c][o][tap] <-> [tap][o][c]) and their gradient fold-back */
-int wm_strided3(const float* in, float* out, int32_t n0, int32_t n1, int32_t n2, int64_t si0, int64_t si1,
-                int64_t si2, int64_t so0, int64_t so1, int64_t so2, int32_t atomic, void* stream);
+int wm_strided3(const float* in, void* out, int32_t out_bf16, int32_t n0, int32_t n1, int32_t n2, int64_t si0,
+                int64_t si1, int64_t si2, int64_t so0, int64_t so1, int64_t so2, int32_t atomic, void* stream);
+/* bf16 copy of (a slice of) the fp32 parameter arena: the B operands of the forward / dX GEMMs in bf16 mode */
+int wm_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 
 /* ---- small direct convolutions (InputProj :814, OutputProj :846, stft_layer :2305,
  * ConvAutoencoder :1700-1709, EncoderTransformerWM.conv2 :1566).  Layout flags: 0 = NCHW,

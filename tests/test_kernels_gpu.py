@@ -464,3 +464,121 @@ def test_droppath_scales(wm):
     ops.step_inc(step)
     ops.droppath_scales(s2, rates, nslots, B, 1234, step)
     assert not torch.equal(s, s2)
+
+
+# ------------------------------------------------------------------ bf16 storage of the wide activations
+def bfr(t):
+    """Round-trip through bf16 (what a bf16-stored tensor holds)."""
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("a_bf,b_bf,c_bf", [(1, 1, 1), (1, 1, 0), (0, 1, 1), (1, 0, 0)])
+def test_gemm_bf16_storage(wm, a_bf, b_bf, c_bf):
+    ops = wm.ops
+    M, N, K = 300, 200, 192
+    x, w = synth_array("hx", (M, K)), synth_array("hw", (N, K), 1.0 / math.sqrt(K))
+    bias, aux = synth_array("hb", (N,)), synth_array("haux", (M, N))
+    xs = dev(x).bfloat16() if a_bf else dev(x)
+    ws = dev(w).bfloat16() if b_bf else dev(w)
+    xr, wr = (bfr(x) if a_bf else x), (bfr(w) if b_bf else w)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16 if c_bf else torch.float32)
+    ops.linear_fwd(xs, ws, dev(bias), out, 1)
+    assert_close(out.float(), xr @ wr.t() + bias, 2e-2, "fwd")
+    ops.linear_fwd(xs, ws, dev(bias), out, 1, a_op=1)
+    assert_close(out.float(), F.gelu(xr) @ wr.t() + bias, 2e-2, "fwd gelu(A)")
+    # dX: B row-contiguous ([N_out=K', K_in=N'] weight), gelu' operand stored like C
+    dy = synth_array("hdy", (M, K))
+    w2 = synth_array("hw2", (K, N), 1.0 / math.sqrt(K))            # [out=K, in=N]
+    dys = dev(dy).bfloat16() if a_bf else dev(dy)
+    w2s = dev(w2).bfloat16() if b_bf else dev(w2)
+    auxs = dev(aux).bfloat16() if c_bf else dev(aux)
+    dx = torch.empty(M, N, device="cuda", dtype=torch.bfloat16 if c_bf else torch.float32)
+    ops.linear_bwd_input(dys, w2s, dx, 1, gaux=auxs)
+    g = torch.autograd.functional.jvp(F.gelu, bfr(aux) if c_bf else aux, torch.ones_like(aux))[1]
+    assert_close(dx.float(), ((bfr(dy) if a_bf else dy) @ (bfr(w2) if b_bf else w2)) * g, 2e-2, "dX")
+    # dW: both operands row-contiguous, ones row, kscale, atomics into fp32
+    act = synth_array("hact", (M, N))
+    acts = dev(act).bfloat16() if b_bf else dev(act)
+    rs = torch.rand((M + 63) // 64) + 0.5
+    dw, db = torch.zeros(K, N, device="cuda"), torch.zeros(K, device="cuda")
+    ops.linear_bwd_weight(dys, acts, dw, db, 1, x_op=1, kscale=dev(rs), k_per_scale=64)
+    dyr = (bfr(dy) if a_bf else dy) * rs.repeat_interleave(64)[:M, None]
+    assert_close(dw, dyr.t() @ F.gelu(bfr(act) if b_bf else act), 3e-2, "dW")
+    assert_close(db, dyr.sum(0), 3e-2, "db")
+
+
+def test_elementwise_kernels_bf16_storage(wm):
+    ops = wm.ops
+    B, hw, C = 2, 16, 64
+    rows = B * hw * hw
+    bf = torch.bfloat16
+    # LayerNorm: bf16 output / bf16 incoming gradient
+    x, gamma, beta = synth_array("ex", (rows, C)), 1 + 0.1 * synth_array("eg", (C,)), 0.1 * synth_array("eb", (C,))
+    y = torch.empty(rows, C, device="cuda", dtype=bf)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(dev(x), dev(gamma), dev(beta), None, y, mean, rstd, hw, 0)
+    assert_close(y.float(), bfr(F.layer_norm(x, (C,), gamma, beta)), 1e-2, "ln fwd bf16")
+    xg = x.clone().requires_grad_()
+    dy = bfr(synth_array("edy", (rows, C)))
+    F.layer_norm(xg, (C,), gamma, beta).backward(dy)
+    dx = torch.empty(rows, C, device="cuda")
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    ops.layernorm_bwd(dev(dy).to(bf), dev(x), dev(gamma), mean, rstd, None, dx, dg, db, None, hw, 0)
+    assert_close(dx, xg.grad, 1e-4, "ln bwd bf16 dy")
+    # window attention with bf16 q|k|v, output and gradients
+    heads = C // 32
+    qkv = bfr(synth_array("eqkv", (rows, 3 * C))).requires_grad_()
+    table = (0.5 * synth_array("etab", (225, heads))).requires_grad_()
+    ref = ref_winattn(qkv, table, B, hw, C, 4)
+    do = bfr(synth_array("edo", ref.shape))
+    ref.backward(do)
+    out = torch.empty(rows, C, device="cuda", dtype=bf)
+    qd = dev(qkv.detach()).to(bf)
+    ops.winattn_fwd(qd, dev(table.detach()), out, B, hw, C, 4, 1)
+    assert_close(out.float(), ref.detach(), 3e-2, "attn fwd bf16 io")
+    dqkv, dtab = torch.empty_like(qd), torch.zeros(225, heads, device="cuda")
+    ops.winattn_bwd(qd, dev(table.detach()), dev(do).to(bf), dqkv, dtab, B, hw, C, 4, 1)
+    assert_close(dqkv.float(), qkv.grad, 5e-2, "attn bwd bf16 io")
+    # depthwise conv
+    Ch = 128
+    h1 = bfr(synth_array("eh1", (B, hw, hw, Ch))).requires_grad_()
+    w = (0.3 * synth_array("ew", (Ch, 1, 3, 3))).requires_grad_()
+    b = 0.1 * synth_array("ebb", (Ch,))
+    refc = F.conv2d(F.gelu(h1).permute(0, 3, 1, 2), w, b, padding=1, groups=Ch).permute(0, 2, 3, 1)
+    g = bfr(synth_array("egc", refc.shape))
+    refc.backward(g)
+    h2 = torch.empty(B, hw, hw, Ch, device="cuda", dtype=bf)
+    hd = dev(h1.detach()).to(bf)
+    ops.dwconv_fwd(hd, dev(w.detach()), dev(b), h2, B, hw, Ch)
+    assert_close(h2.float(), refc.detach(), 1e-2, "dwconv fwd bf16")
+    dh1 = torch.empty_like(hd)
+    dwg, dbg = torch.zeros(Ch, 9, device="cuda"), torch.zeros(Ch, device="cuda")
+    ops.dwconv_bwd(hd, dev(g).to(bf), dev(w.detach()), dh1, dwg, dbg, B, hw, Ch)
+    assert_close(dh1.float(), h1.grad, 1e-2, "dwconv bwd bf16")
+    assert_close(dwg, w.grad.reshape(Ch, 9), 1e-3, "dwconv dw bf16")
+    # im2col / col2im / pixel (un)shuffle / strided3 / cast
+    xt = synth_array("ei", (B, hw, hw, 32))
+    cols32 = torch.empty(B * 64, 16 * 32, device="cuda")
+    cols16 = torch.empty(B * 64, 16 * 32, device="cuda", dtype=bf)
+    ops.im2col(dev(xt), cols32, B, hw, 32)
+    ops.im2col(dev(xt), cols16, B, hw, 32)
+    assert torch.equal(cols16.float(), bfr(cols32.cpu()).cuda())
+    d32, d16 = torch.empty(B, hw, hw, 32, device="cuda"), torch.empty(B, hw, hw, 32, device="cuda")
+    ops.col2im(cols16.float(), d32, B, hw, 32)
+    ops.col2im(cols16, d16, B, hw, 32)
+    assert_close(d16, d32, 1e-6, "col2im bf16")
+    y4 = synth_array("ey4", (B * 64, 4 * 32))
+    a32, a16 = torch.zeros(B, 16, 16, 32, device="cuda"), torch.zeros(B, 16, 16, 32, device="cuda")
+    ops.pixel_shuffle(dev(bfr(y4)), None, a32, B, 8, 32, 32, 0)
+    ops.pixel_shuffle(dev(y4).to(bf), None, a16, B, 8, 32, 32, 0)
+    assert torch.equal(a32, a16)
+    u16 = torch.empty(B * 64, 4 * 32, device="cuda", dtype=bf)
+    ops.pixel_unshuffle(a32, u16, B, 8, 32, 32, 0)
+    assert torch.equal(u16.float().cpu(), bfr(y4))
+    src = dev(synth_array("es3", (6, 5, 8)))
+    o16 = torch.empty(6, 8, 5, device="cuda", dtype=bf)
+    ops.strided3(src, o16, (6, 8, 5), (40, 1, 8), (40, 5, 1))
+    assert torch.equal(o16.float(), src.permute(0, 2, 1).to(bf).float())
+    c16 = torch.empty(src.numel(), device="cuda", dtype=bf)
+    ops.cast_bf16(src, c16, src.numel())
+    assert torch.equal(c16, src.flatten().to(bf))
