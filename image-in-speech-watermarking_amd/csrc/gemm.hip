@@ -129,55 +129,63 @@ template <int R, int BK> struct TileRegsH {
   static constexpr int TPR = BK / 8;                       // threads per row (K-contiguous)
   static constexpr int RPP = 256 / TPR;
   static constexpr int KC_N = (R + RPP - 1) / RPP;
-  static constexpr int NBLK = (R / 8) * (BK / 8);          // 8x8 blocks (row-contiguous source)
-  static constexpr int BPT = (NBLK + 255) / 256;           // blocks per thread
-  static constexpr int N = KC_N > 8 * BPT ? KC_N : 8 * BPT;
-  uint4 v[N];
+  // row-contiguous source (transposing): one unit = RW rows x 8 k; RW chosen so that ~256 units exist per tile
+  static constexpr int RW = R >= 256 ? 8 : (R >= 128 ? 4 : 2);
+  static constexpr int NU = (R / RW) * (BK / 8);
+  static constexpr int UPT = (NU + 255) / 256;             // units per thread
+  static constexpr int WPL = RW / 2;                       // 32-bit words per k-line of a unit
+  static constexpr int NW = UPT * 8 * WPL;                 // words held for the transposing path
+  static constexpr int N = (4 * KC_N > NW ? 4 * KC_N : NW);
+  uint32_t w[N];
 };
 
 template <int R, int BK>
 __device__ __forceinline__ void load_tile_h(TileRegsH<R, BK>& t, const __bf16* __restrict__ p, bool kc, int64_t ld,
                                             int row0, int rmax, int k0, int kend, bool ones, int tid) {
   using TR = TileRegsH<R, BK>;
-  const uint4 zero = make_uint4(0, 0, 0, 0), one = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
   if (kc) {
     const int r = tid / TR::TPR, kq = tid % TR::TPR;
     const int k = k0 + 8 * kq;
 #pragma unroll
     for (int q = 0; q < TR::KC_N; ++q) {
       const int rl = r + TR::RPP * q, row = row0 + rl;
-      uint4 v = zero;
+      uint4 v = make_uint4(0, 0, 0, 0);
       if (rl < R && k < kend) {
         if (row < rmax) v = *reinterpret_cast<const uint4*>(p + (int64_t)row * ld + k);
-        else if (ones && row == rmax) v = one;
+        else if (ones && row == rmax) v = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
       }
-      t.v[q] = v;
+      t.w[4 * q + 0] = v.x; t.w[4 * q + 1] = v.y; t.w[4 * q + 2] = v.z; t.w[4 * q + 3] = v.w;
     }
   } else {
+    constexpr int RW = TR::RW, WPL = TR::WPL;
 #pragma unroll
-    for (int bq = 0; bq < TR::BPT; ++bq) {
-      const int blk = tid + 256 * bq;
-      const int kb = blk / (R / 8), r8 = blk % (R / 8);
-      const int row = row0 + 8 * r8;
+    for (int uq = 0; uq < TR::UPT; ++uq) {
+      const int u = tid + 256 * uq;
+      const int kb = u / (R / RW), rg = u % (R / RW);
+      const int row = row0 + RW * rg;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = k0 + 8 * kb + i;
-        uint4 v = zero;
-        if (blk < TR::NBLK && k < kend) {
-          const __bf16* src = p + (int64_t)k * ld + row;
-          if (row + 7 < rmax) {
-            v = *reinterpret_cast<const uint4*>(src);
-          } else {
-            uint16_t e[8];
+        uint32_t wv[WPL];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+        for (int x = 0; x < WPL; ++x) wv[x] = 0;
+        if (u < TR::NU && k < kend) {
+          const __bf16* src = p + (int64_t)k * ld + row;
+          if (row + RW - 1 < rmax) {
+            if constexpr (WPL == 1) wv[0] = *reinterpret_cast<const uint32_t*>(src);
+            else if constexpr (WPL == 2) { const uint2 v = *reinterpret_cast<const uint2*>(src); wv[0] = v.x; wv[1] = v.y; }
+            else { const uint4 v = *reinterpret_cast<const uint4*>(src); wv[0] = v.x; wv[1] = v.y; wv[2] = v.z; wv[3] = v.w; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
               const int rr = row + j;
-              e[j] = rr < rmax ? reinterpret_cast<const uint16_t*>(src)[j] : ((ones && rr == rmax) ? 0x3F80 : 0);
+              const uint32_t e = rr < rmax ? reinterpret_cast<const uint16_t*>(src)[j] : ((ones && rr == rmax) ? 0x3F80u : 0u);
+              wv[j >> 1] |= e << (16 * (j & 1));
             }
-            v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
           }
         }
-        t.v[bq * 8 + i] = v;
+#pragma unroll
+        for (int x = 0; x < WPL; ++x) t.w[(uq * 8 + i) * WPL + x] = wv[x];
       }
     }
   }
@@ -189,53 +197,47 @@ __device__ __forceinline__ void store_tile_h(const TileRegsH<R, BK>& t, __bf16* 
                                              int tid) {
   using TR = TileRegsH<R, BK>;
   constexpr int LD = BK + LdsT<__bf16>::PAD;
+  const bool scaled = kscale != nullptr;
   if (kc) {
     const int r = tid / TR::TPR, kq = tid % TR::TPR;
     float sc = 1.f;
-    const bool scaled = kscale != nullptr;
     if (scaled) sc = kscale[(k0 + 8 * kq) / kps];
 #pragma unroll
     for (int q = 0; q < TR::KC_N; ++q) {
       const int rl = r + TR::RPP * q;
       if (rl < R) {
-        uint4 v = t.v[q];
+        uint32_t w[4] = {t.w[4 * q], t.w[4 * q + 1], t.w[4 * q + 2], t.w[4 * q + 3]};
         const bool real = row0 + rl < rmax;
         if ((op && real) || scaled) {
-          uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float a = bf_lo(w[j]), b = bf_hi(w[j]);
             if (op && real) { a = apply_op(a, op); b = apply_op(b, op); }
             w[j] = pack_bf2(a * sc, b * sc);
           }
-          v = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        *reinterpret_cast<uint4*>(s + rl * LD + 8 * kq) = v;
+        *reinterpret_cast<uint4*>(s + rl * LD + 8 * kq) = make_uint4(w[0], w[1], w[2], w[3]);
       }
     }
   } else {
+    constexpr int RW = TR::RW, WPL = TR::WPL;
 #pragma unroll
-    for (int bq = 0; bq < TR::BPT; ++bq) {
-      const int blk = tid + 256 * bq;
-      if (blk < TR::NBLK) {
-        const int kb = blk / (R / 8), r8 = blk % (R / 8);
+    for (int uq = 0; uq < TR::UPT; ++uq) {
+      const int u = tid + 256 * uq;
+      if (u < TR::NU) {
+        const int kb = u / (R / RW), rg = u % (R / RW);
         float sc = 1.f;
-        const bool scaled = kscale != nullptr;
         if (scaled) sc = kscale[(k0 + 8 * kb) / kps];
-        // 8x8 transpose: source register i holds rows 8*r8..+7 at k = 8*kb + i
-        uint32_t src[8][4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { src[i][0] = t.v[bq * 8 + i].x; src[i][1] = t.v[bq * 8 + i].y; src[i][2] = t.v[bq * 8 + i].z; src[i][3] = t.v[bq * 8 + i].w; }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {                       // output row j: k = 0..7
-          const int rl = 8 * r8 + j;
+        for (int j = 0; j < RW; ++j) {                      // output row j of the unit: k = 0..7 from word (j>>1) of each k-line
+          const int rl = RW * rg + j;
           const bool real = row0 + rl < rmax;
           uint32_t o[4];
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
-            const uint32_t a = src[2 * kk][j >> 1], b = src[2 * kk + 1][j >> 1];
-            uint32_t lo = (j & 1) ? (a >> 16) : (a & 0xffffu);
-            uint32_t hi = (j & 1) ? (b & 0xffff0000u) : (b << 16);
+            const uint32_t a = t.w[(uq * 8 + 2 * kk) * WPL + (j >> 1)], b = t.w[(uq * 8 + 2 * kk + 1) * WPL + (j >> 1)];
+            const uint32_t lo = (j & 1) ? (a >> 16) : (a & 0xffffu);
+            const uint32_t hi = (j & 1) ? (b & 0xffff0000u) : (b << 16);
             if ((op && real) || scaled) {
               float fa = __uint_as_float(lo << 16), fb = __uint_as_float(hi);
               if (op && real) { fa = apply_op(fa, op); fb = apply_op(fb, op); }
@@ -314,7 +316,8 @@ template <int TM, int TN, int BK> struct TileMma<float, TM, TN, BK> {
 };
 
 template <typename LT, typename AT, typename BT, int WM, int WN, int TM, int TN, int BK>
-__global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int klen, const bool vec_ok) {
+__global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int klen, const bool vec_ok, const int tiles_n,
+                                                   const int tiles_m, const int ksplit) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int LD = BK + LdsT<LT>::PAD;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -324,8 +327,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int kle
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * klen;
+  // XCD-aware tile order (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, each
+  // with a private L2.  Workgroups that re-read the same activation slab are given ids that are equal mod 8:
+  //   plain GEMM  - all column tiles of one row tile (they share the A row slab),
+  //   split-K dW  - all output tiles of one K range (they share both K slabs).
+  int bx, by, bz;
+  {
+    const int L = blockIdx.x, j = L & 7, sq = L >> 3;
+    if (ksplit > 1) {
+      const int tiles = tiles_n * tiles_m, t = sq % tiles;
+      bz = (sq / tiles) * 8 + j;
+      bx = t % tiles_n; by = t / tiles_n;
+      if (bz >= ksplit) return;
+    } else {
+      bz = 0;
+      bx = sq % tiles_n;
+      by = (sq / tiles_n) * 8 + j;
+      if (by >= tiles_m) return;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * klen;
   const int kend = min(g.K, kbeg + klen);
 
   f32x16 acc[TM][TN];
@@ -482,10 +504,12 @@ int launch(const WmGemm& g, int ksplit, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
-  dim3 grid(p.tiles_n, p.tiles_m, p.ksplit);
+  const int groups = p.ksplit > 1 ? (p.ksplit + 7) / 8 * p.tiles_n * p.tiles_m : (p.tiles_m + 7) / 8 * p.tiles_n;
+  dim3 grid(8 * groups);
   const bool vec_ok = al16(g.C) && !(g.ldc & 7) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && !(g.ldr & 3))) &&
                       (!g.gaux || (al16(g.gaux) && !(g.ldg & 7)));
-  hipLaunchKernelGGL((gemm_kernel<LT, AT, BT, WM, WN, TM, TN, BK>), grid, dim3(256), smem, st, g, p.klen, vec_ok);
+  hipLaunchKernelGGL((gemm_kernel<LT, AT, BT, WM, WN, TM, TN, BK>), grid, dim3(256), smem, st, g, p.klen, vec_ok,
+                     p.tiles_n, p.tiles_m, p.ksplit);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
@@ -509,6 +533,8 @@ int dispatch(const WmGemm& g, int ksplit, hipStream_t st) {
 
 }  // namespace
 
+int wm_gemm_tn_bf16(const WmGemm& g, hipStream_t st);     // gemm_tn.hip
+
 extern "C" int wm_abi_version(void) { return 1; }
 
 extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
@@ -527,6 +553,8 @@ extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
   if (g.rowscale && g.rows_per_scale <= 0) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (g.mode == 0) return dispatch<float, float, float, 32>(g, g.ksplit, st);
+  if (g.mode == 1 && !g.a_kc && !g.b_kc && g.atomic_out && !g.a_op && !g.c_bf16 && !getenv("WM_NO_TN"))
+    return wm_gemm_tn_bf16(g, st);                          // weight gradients: transposing-LDS-read kernel
   if (g.mode == 1) {
     if (g.a_bf16 && g.b_bf16) return dispatch<__bf16, __bf16, __bf16, 64>(g, g.ksplit, st);
     if (g.a_bf16) return dispatch<__bf16, __bf16, float, 64>(g, g.ksplit, st);

@@ -207,14 +207,14 @@ class UformerAudio(nn.Module):
         seg_c = (_conv_specs("stft_layer.0.", 4, in_chans, 3, 3) + _conv_specs("stft_layer.2.", in_chans, 4, 3, 3) +
                  _trunk_specs(a, "decoder_wm.", True))
         self._specs = seg_a + seg_b + seg_c + unused
-        # every tensor starts on a 16-byte boundary (float4 loads); q|kv weights and biases stay adjacent because
-        # their sizes are multiples of 4 floats
+        # every tensor starts on a 32-byte boundary: 16-B loads stay aligned in the fp32 arena AND in its bf16 copy;
+        # q|kv weights and biases stay adjacent because their sizes are multiples of 8 elements
         self._offsets, self._seg_sizes, off = {}, [], 0
         for seg in (seg_a, seg_b, seg_c, unused):
             start = off
             for name, shape, _ in seg:
                 self._offsets[name] = off
-                off += (math.prod(shape) + 3) // 4 * 4
+                off += (math.prod(shape) + 7) // 8 * 8
             self._seg_sizes.append(off - start)
         self._build_arena(torch.device("cpu"), init=True)
         self._anchor = None

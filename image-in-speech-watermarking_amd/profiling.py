@@ -69,7 +69,11 @@ class KernelTimer:
             n_eff = N + (1 if kwargs.get("b_ones") else 0)
             cd = lambda a, b: (a + b - 1) // b
             ks = 4 if kwargs.get("atomic_out") else 1
-            if n_eff <= 32:
+            a_kc = args[9] if len(args) > 9 else kwargs.get("a_kc", 1)
+            b_kc = args[10] if len(args) > 10 else kwargs.get("b_kc", 1)
+            if mode == 1 and not a_kc and not b_kc and kwargs.get("atomic_out"):
+                tile = "tn_" + ("128x128" if (M > 64 and N > 64) else ("128x64" if M > 64 else "64x64"))
+            elif n_eff <= 32:
                 tile = "256x32"
             elif n_eff > 64 and cd(M, 128) * cd(n_eff, 128) * ks >= 384:
                 tile = "128x128"

@@ -112,9 +112,11 @@ def test_bf16_mode_bits_and_deviation(net, golden):
     net.eval()
     net.compute_mode = "bf16"
     x, msg = synth_tile(2, "g3_x").cuda(), synth_bits("g3_msg", (2, 1, 32, 32)).cuda()
-    with torch.no_grad():
-        out = net(x, msg)
-    net.compute_mode = "fp32"
+    try:
+        with torch.no_grad():
+            out = net(x, msg)
+    finally:
+        net.compute_mode = "fp32"
     dev = {k: rel(o, g[k]) for o, k in zip(out, ("stft_new", "noise", "wm_pred", "wm"))}
     print("bf16 deviation vs fp32 reference:", dev)
     assert max(dev.values()) < 0.1
