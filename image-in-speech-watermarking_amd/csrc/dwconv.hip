@@ -63,13 +63,16 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ST* __restrict__ 
   }
 }
 
-// dh1 = gelu'(h1) * sum_k w[k] * dh2[p - off_k];  dw[c][k] += sum_p dh2[p] * gelu(h1)[p + off_k]; db += sum_p dh2
+// dh1 = gelu'(h1) * sum_k w[k] * dh2[p - off_k];  dw[c][k] += sum_q gelu(h1)[q] * dh2[q - off_k];  db += sum dh2.
+// Only dh2 needs a halo: the weight gradient is written as a sum over the CENTRE pixels q of a1[q] * dh2[q - off]
+// (zero padding of the dh2 halo outside the image makes it equal to the usual sum over p of dh2[p] * a1[p + off]),
+// so every tap needs ONE LDS read that feeds both the transposed convolution and the weight gradient, and
+// gelu / gelu' of h1 are evaluated once per element from one shared exp().
 template <typename ST>
-__global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(const ST* __restrict__ h1, const ST* __restrict__ dh2,
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ST* __restrict__ h1, const ST* __restrict__ dh2,
                                                          const float* __restrict__ w, ST* __restrict__ dh1,
                                                          float* __restrict__ dw, float* __restrict__ db, int B,
                                                          int hw, int Ch) {
-  __shared__ __attribute__((aligned(16))) float ta[HP * HP * TC];      // gelu(h1) with halo
   __shared__ __attribute__((aligned(16))) float tg[HP * HP * TC];      // dh2 with halo
   __shared__ float wacc[TC * 10];
   const int tid = threadIdx.x, nt = hw / TP;
@@ -86,13 +89,26 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(const ST* __restrict
   for (int i = tid; i < TC * 10; i += 256) wacc[i] = 0.f;
   for (int tx = 0; tx < nt; ++tx) {
     __syncthreads();
-    load_halo_tile(ta, h1, b, ty, tx, hw, Ch, cbase, true, tid);
     load_halo_tile(tg, dh2, b, ty, tx, hw, Ch, cbase, false, tid);
     __syncthreads();
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {                          // one pixel at a time: 76 live accumulators/weights already
+    for (int q = 0; q < 4; ++q) {
       const int pix = pg * 4 + q, py = pix >> 3, px = pix & 7;
-      const float4 gc = *reinterpret_cast<const float4*>(tg + ((py + 1) * HP + px + 1) * TC + 4 * c4);
+      const int gy = ty * TP + py, gx = tx * TP + px;
+      const int64_t off = (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4;
+      const float4 hv = IO<ST>::ld4(h1 + off);
+      float a1[4], gp[4];
+      {
+        const float xs[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float e = __expf(-0.5f * xs[cc] * xs[cc]);
+          const float t = phi_tail_f(xs[cc], e);
+          const float cdf = xs[cc] >= 0.f ? 1.0f - t : t;
+          a1[cc] = xs[cc] * cdf;
+          gp[cc] = cdf + xs[cc] * 0.39894228040143268f * e;
+        }
+      }
       float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
@@ -101,15 +117,11 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(const ST* __restrict
           const int k = dy * 3 + dx;
           const float4 g = *reinterpret_cast<const float4*>(tg + ((py + 2 - dy) * HP + px + 2 - dx) * TC + 4 * c4);
           o[0] += wr[0][k] * g.x; o[1] += wr[1][k] * g.y; o[2] += wr[2][k] * g.z; o[3] += wr[3][k] * g.w;
-          const float4 a = *reinterpret_cast<const float4*>(ta + ((py + dy) * HP + px + dx) * TC + 4 * c4);
-          aw[0][k] += gc.x * a.x; aw[1][k] += gc.y * a.y; aw[2][k] += gc.z * a.z; aw[3][k] += gc.w * a.w;
+          aw[0][k] += a1[0] * g.x; aw[1][k] += a1[1] * g.y; aw[2][k] += a1[2] * g.z; aw[3][k] += a1[3] * g.w;
         }
+      const float4 gc = *reinterpret_cast<const float4*>(tg + ((py + 1) * HP + px + 1) * TC + 4 * c4);
       ab[0] += gc.x; ab[1] += gc.y; ab[2] += gc.z; ab[3] += gc.w;
-      const int gy = ty * TP + py, gx = tx * TP + px;
-      const int64_t off = (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4;
-      const float4 hv = IO<ST>::ld4(h1 + off);
-      IO<ST>::st4(dh1 + off, make_float4(o[0] * gelu_grad_f(hv.x), o[1] * gelu_grad_f(hv.y), o[2] * gelu_grad_f(hv.z),
-                                          o[3] * gelu_grad_f(hv.w)));
+      IO<ST>::st4(dh1 + off, make_float4(o[0] * gp[0], o[1] * gp[1], o[2] * gp[2], o[3] * gp[3]));
     }
   }
 #pragma unroll

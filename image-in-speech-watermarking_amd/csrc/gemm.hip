@@ -12,6 +12,7 @@
 // picked per launch so that the grid covers the 256 CUs (small-M stages use 64x64 tiles).
 #include <cstdlib>
 #include "common.h"
+#include "tn_stage.h"
 #include "../../include/wm_kernels.h"
 
 namespace {
@@ -273,6 +274,9 @@ template <int R, int BK> struct Stager<__bf16, R, BK, __bf16> {
   }
 };
 
+template <typename BT, int R, int BK, typename LT, bool TR> struct BStager { using type = Stager<BT, R, BK, LT>; };
+template <typename BT, int R, int BK> struct BStager<BT, R, BK, __bf16, true> { using type = TnStage<BT, R, BK>; };
+
 // TM x TN register-blocked MFMA over one K-tile held in LDS
 template <typename LT, int TM, int TN, int BK> struct TileMma;
 template <int TM, int TN, int BK> struct TileMma<__bf16, TM, TN, BK> {
@@ -315,14 +319,18 @@ template <int TM, int TN, int BK> struct TileMma<float, TM, TN, BK> {
   }
 };
 
-template <typename LT, typename AT, typename BT, int WM, int WN, int TM, int TN, int BK>
+// B_TR: the B operand is row-contiguous bf16 (dX: the [out,in] weight read along `in`): staged as it lies ([k][n]) and
+// read through transposing LDS reads instead of being transposed with VALU shuffles.
+template <typename LT, typename AT, typename BT, bool B_TR, int WM, int WN, int TM, int TN, int BK>
 __global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int klen, const bool vec_ok, const int tiles_n,
                                                    const int tiles_m, const int ksplit) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int LD = BK + LdsT<LT>::PAD;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int LDBT = BN + 32;                              // row stride of the as-it-lies B image
+  constexpr int BSZ = B_TR ? BK * LDBT : BN * LD;            // elements per B buffer
   LT* As = reinterpret_cast<LT*>(smem_raw);                  // [2][BM*LD]
-  LT* Bs = As + 2 * BM * LD;                                 // [2][BN*LD]
+  LT* Bs = As + 2 * BM * LD;                                 // [2][BSZ]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -359,11 +367,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int kle
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   Stager<AT, BM, BK, LT> ra;
-  Stager<BT, BN, BK, LT> rb;
+  typename BStager<BT, BN, BK, LT, B_TR>::type rb;
   ra.load(g.A, g.a_kc, g.lda, m0, g.M, kbeg, kend, false, tid);
-  rb.load(g.B, g.b_kc, g.ldb, n0, g.N, kbeg, kend, g.b_ones != 0, tid);
   ra.store(As, g.a_kc, g.a_op, g.kscale, g.k_per_scale, m0, g.M, kbeg, tid);
-  rb.store(Bs, g.b_kc, g.b_op, nullptr, 1, n0, g.N, kbeg, tid);
+  if constexpr (B_TR) {
+    rb.load(g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+    rb.store(reinterpret_cast<__bf16*>(Bs), g.b_op, nullptr, 1, kbeg, tid);
+  } else {
+    rb.load(g.B, g.b_kc, g.ldb, n0, g.N, kbeg, kend, g.b_ones != 0, tid);
+    rb.store(Bs, g.b_kc, g.b_op, nullptr, 1, n0, g.N, kbeg, tid);
+  }
   __syncthreads();
 
   int buf = 0;
@@ -371,13 +384,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int kle
     const bool more = k0 + BK < kend;
     if (more) {
       ra.load(g.A, g.a_kc, g.lda, m0, g.M, k0 + BK, kend, false, tid);
-      rb.load(g.B, g.b_kc, g.ldb, n0, g.N, k0 + BK, kend, g.b_ones != 0, tid);
+      if constexpr (B_TR) rb.load(g.B, g.ldb, n0, g.N, k0 + BK, kend, tid);
+      else rb.load(g.B, g.b_kc, g.ldb, n0, g.N, k0 + BK, kend, g.b_ones != 0, tid);
     }
-    TileMma<LT, TM, TN, BK>::run(acc, As + buf * BM * LD + ((wm * TM) * 32 + r) * LD,
-                                 Bs + buf * BN * LD + ((wn * TN) * 32 + r) * LD, h);
+    if constexpr (B_TR) {
+      const __bf16* Ab = reinterpret_cast<const __bf16*>(As) + buf * BM * LD + ((wm * TM) * 32 + r) * LD;
+      const __bf16* Bb = reinterpret_cast<const __bf16*>(Bs) + buf * BSZ;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LD + 16 * ks + 8 * h);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = tr_frag(Bb, LDBT, (wn * TN + j) * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      TileMma<LT, TM, TN, BK>::run(acc, As + buf * BM * LD + ((wm * TM) * 32 + r) * LD,
+                                   Bs + buf * BSZ + ((wn * TN) * 32 + r) * LD, h);
+    }
     if (more) {
       ra.store(As + (buf ^ 1) * BM * LD, g.a_kc, g.a_op, g.kscale, g.k_per_scale, m0, g.M, k0 + BK, tid);
-      rb.store(Bs + (buf ^ 1) * BN * LD, g.b_kc, g.b_op, nullptr, 1, n0, g.N, k0 + BK, tid);
+      if constexpr (B_TR) rb.store(reinterpret_cast<__bf16*>(Bs) + (buf ^ 1) * BSZ, g.b_op, nullptr, 1, k0 + BK, tid);
+      else rb.store(Bs + (buf ^ 1) * BSZ, g.b_kc, g.b_op, nullptr, 1, n0, g.N, k0 + BK, tid);
     }
     __syncthreads();
     buf ^= 1;
@@ -490,17 +522,18 @@ Plan make_plan(const WmGemm& g, int ksplit) {
   return p;
 }
 
-template <typename LT, typename AT, typename BT, int WM, int WN, int TM, int TN, int BK>
+template <typename LT, typename AT, typename BT, bool B_TR, int WM, int WN, int TM, int TN, int BK>
 int launch(const WmGemm& g, int ksplit, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int LD = BK + LdsT<LT>::PAD;
-  constexpr size_t stage = sizeof(LT) * 2 * (BM + BN) * LD, ctile = sizeof(float) * BM * (BN + 4);
+  constexpr size_t bsz = B_TR ? BK * (BN + 32) : BN * LD;
+  constexpr size_t stage = sizeof(LT) * 2 * (BM * LD + bsz), ctile = sizeof(float) * BM * (BN + 4);
   constexpr size_t smem = stage > ctile ? stage : ctile;
   const Plan p = make_plan<BM, BN, BK>(g, ksplit);
   static bool attr = false;
   if (!attr) {
     if (smem > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<LT, AT, BT, WM, WN, TM, TN, BK>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<LT, AT, BT, B_TR, WM, WN, TM, TN, BK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
@@ -508,7 +541,7 @@ int launch(const WmGemm& g, int ksplit, hipStream_t st) {
   dim3 grid(8 * groups);
   const bool vec_ok = al16(g.C) && !(g.ldc & 7) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && !(g.ldr & 3))) &&
                       (!g.gaux || (al16(g.gaux) && !(g.ldg & 7)));
-  hipLaunchKernelGGL((gemm_kernel<LT, AT, BT, WM, WN, TM, TN, BK>), grid, dim3(256), smem, st, g, p.klen, vec_ok,
+  hipLaunchKernelGGL((gemm_kernel<LT, AT, BT, B_TR, WM, WN, TM, TN, BK>), grid, dim3(256), smem, st, g, p.klen, vec_ok,
                      p.tiles_n, p.tiles_m, p.ksplit);
   WM_CHECK_LAUNCH();
   return WM_OK;
@@ -516,19 +549,19 @@ int launch(const WmGemm& g, int ksplit, hipStream_t st) {
 
 // Tile choice: the largest tile whose grid still gives every CU at least ~1.5 workgroups; the transformer's
 // coarse stages (M = B*256 or B*64 tokens) otherwise leave most of the 256 CUs idle behind 128x128 tiles.
-template <typename LT, typename AT, typename BT, int BK>
+template <typename LT, typename AT, typename BT, bool B_TR, int BK>
 int dispatch(const WmGemm& g, int ksplit, hipStream_t st) {
   const int ncols = g.N + (g.b_ones ? 1 : 0);
-  if (ncols <= 32) return launch<LT, AT, BT, 4, 1, 2, 1, BK>(g, ksplit, st);           // 256 x 32
+  if (ncols <= 32) return launch<LT, AT, BT, B_TR, 4, 1, 2, 1, BK>(g, ksplit, st);           // 256 x 32
   const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((ncols + 127) / 128);
   const int64_t t12864 = (int64_t)((g.M + 127) / 128) * ((ncols + 63) / 64);
   const int64_t want = 384;
   // weight-gradient GEMMs get ~4x more workgroups from split-K; more splits than that cost more in fp32 atomics
   // (1.3 TB/s chip-wide) than the larger tile saves in operand re-reads (measured: 128x128 + deep split-K was slower)
   const int ks = g.atomic_out ? 4 : 1;
-  if (ncols > 64 && t128 * ks >= want) return launch<LT, AT, BT, 2, 2, 2, 2, BK>(g, ksplit, st);       // 128 x 128
-  if (t12864 * ks >= want || g.M >= 32768) return launch<LT, AT, BT, 2, 2, 2, 1, BK>(g, ksplit, st);   // 128 x 64
-  return launch<LT, AT, BT, 2, 2, 1, 1, BK>(g, ksplit, st);                            // 64 x 64
+  if (ncols > 64 && t128 * ks >= want) return launch<LT, AT, BT, B_TR, 2, 2, 2, 2, BK>(g, ksplit, st);       // 128 x 128
+  if (t12864 * ks >= want || g.M >= 32768) return launch<LT, AT, BT, B_TR, 2, 2, 2, 1, BK>(g, ksplit, st);   // 128 x 64
+  return launch<LT, AT, BT, B_TR, 2, 2, 1, 1, BK>(g, ksplit, st);                            // 64 x 64
 }
 
 }  // namespace
@@ -552,14 +585,18 @@ extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
   if (g.kscale && (g.k_per_scale <= 0 || (g.k_per_scale & 3))) return WM_EINVAL;
   if (g.rowscale && g.rows_per_scale <= 0) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (g.mode == 0) return dispatch<float, float, float, 32>(g, g.ksplit, st);
+  if (g.mode == 0) return dispatch<float, float, float, false, 32>(g, g.ksplit, st);
   if (g.mode == 1 && !g.a_kc && !g.b_kc && g.atomic_out && !g.a_op && !g.c_bf16 && !getenv("WM_NO_TN"))
     return wm_gemm_tn_bf16(g, st);                          // weight gradients: transposing-LDS-read kernel
   if (g.mode == 1) {
-    if (g.a_bf16 && g.b_bf16) return dispatch<__bf16, __bf16, __bf16, 64>(g, g.ksplit, st);
-    if (g.a_bf16) return dispatch<__bf16, __bf16, float, 64>(g, g.ksplit, st);
-    if (g.b_bf16) return dispatch<__bf16, float, __bf16, 64>(g, g.ksplit, st);
-    return dispatch<__bf16, float, float, 64>(g, g.ksplit, st);
+    // dX form with a bf16 weight copy: B read through transposing LDS reads (no VALU transposes)
+    const bool btr = g.a_kc && !g.b_kc && g.b_bf16 && !g.b_ones && !(g.ldb & 7) && !getenv("WM_NO_TN");
+    if (btr) return g.a_bf16 ? dispatch<__bf16, __bf16, __bf16, true, 64>(g, g.ksplit, st)
+                             : dispatch<__bf16, float, __bf16, true, 64>(g, g.ksplit, st);
+    if (g.a_bf16 && g.b_bf16) return dispatch<__bf16, __bf16, __bf16, false, 64>(g, g.ksplit, st);
+    if (g.a_bf16) return dispatch<__bf16, __bf16, float, false, 64>(g, g.ksplit, st);
+    if (g.b_bf16) return dispatch<__bf16, float, __bf16, false, 64>(g, g.ksplit, st);
+    return dispatch<__bf16, float, float, false, 64>(g, g.ksplit, st);
   }
   return WM_EINVAL;
 }
