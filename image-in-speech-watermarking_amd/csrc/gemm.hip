@@ -566,7 +566,7 @@ int dispatch(const WmGemm& g, int ksplit, hipStream_t st) {
 
 }  // namespace
 
-int wm_gemm_tn_bf16(const WmGemm& g, hipStream_t st);     // gemm_tn.hip
+int wm_gemm_fast_bf16(const WmGemm& g, hipStream_t st);   // gemm_fast.hip: branch-free bf16 kernels, -1 = not applicable
 
 extern "C" int wm_abi_version(void) { return 1; }
 
@@ -586,13 +586,11 @@ extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
   if (g.rowscale && g.rows_per_scale <= 0) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (g.mode == 0) return dispatch<float, float, float, false, 32>(g, g.ksplit, st);
-  if (g.mode == 1 && !g.a_kc && !g.b_kc && g.atomic_out && !g.a_op && !g.c_bf16 && !getenv("WM_NO_TN"))
-    return wm_gemm_tn_bf16(g, st);                          // weight gradients: transposing-LDS-read kernel
   if (g.mode == 1) {
-    // dX form with a bf16 weight copy: B read through transposing LDS reads (no VALU transposes)
-    const bool btr = g.a_kc && !g.b_kc && g.b_bf16 && !g.b_ones && !(g.ldb & 7) && !getenv("WM_NO_TN");
-    if (btr) return g.a_bf16 ? dispatch<__bf16, __bf16, __bf16, true, 64>(g, g.ksplit, st)
-                             : dispatch<__bf16, float, __bf16, true, 64>(g, g.ksplit, st);
+    const int rc = wm_gemm_fast_bf16(g, st);
+    if (rc >= 0) return rc;
+  }
+  if (g.mode == 1) {
     if (g.a_bf16 && g.b_bf16) return dispatch<__bf16, __bf16, __bf16, false, 64>(g, g.ksplit, st);
     if (g.a_bf16) return dispatch<__bf16, __bf16, float, false, 64>(g, g.ksplit, st);
     if (g.b_bf16) return dispatch<__bf16, float, __bf16, false, 64>(g, g.ksplit, st);

@@ -1,0 +1,439 @@
+// bf16-MFMA GEMMs of the train step with BRANCH-FREE operand staging (mode 1).
+//
+// The first generic kernel (gemm.hip) guards every global load with its own bounds branch and picks layouts at run
+// time; its K loop compiled to ~1600 basic blocks in which loads are issued one at a time behind exec-mask
+// branches, so each K tile paid several full memory latencies (measured 15k cycles per K tile against 512 cycles of
+// MFMA).  Here every layout decision is a template parameter, addresses are clamped instead of guarded (out-of-range
+// lanes load a valid address and the value is zeroed with a select), and row pointers are set up once before the
+// loop, so a K tile is: N back-to-back 16-byte loads -> MFMAs of the previous tile -> 16-byte LDS stores -> barrier.
+//
+//   gemm_nt_kernel   C[M,N] = epi(A[M,K] * B^T),  A K-contiguous (fp32 or bf16),
+//                    B K-contiguous ([N,K], forward) or row-contiguous ([K,N], dX; read with ds_read_b64_tr_b16)
+//   gemm_tn_kernel   C[M,N] += A[K,M]^T B[K,N] (+ column sums of A): weight gradients, split-K, fp32 atomics
+#include <cstdlib>
+#include "common.h"
+#include "../../include/wm_kernels.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+// MFMA 32x32x16 operand out of an as-it-lies [k][columns] LDS image (lane l: column l&31, k = 8*(l>>5) + j)
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int col0, int kstep, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const __bf16* a = tile + (16 * kstep + 8 * (g >> 1) + q) * ld + col0 + 16 * (g & 1) + 4 * p;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * ld));
+  bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return f;
+}
+
+template <typename ST> struct Chunk;                       // one 16-byte global load
+template <> struct Chunk<__bf16> {
+  static constexpr int E = 8;
+  uint4 v;
+  __device__ __forceinline__ void ld(const __bf16* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void zero_if(bool z) { if (z) v = make_uint4(0, 0, 0, 0); }
+  template <bool GELU> __device__ __forceinline__ void st(__bf16* s, float sc, bool scaled) const {
+    uint4 x = v;
+    if (GELU || scaled) {
+      uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = bf_lo(w[j]), b = bf_hi(w[j]);
+        if (GELU) { a = gelu_f(a); b = gelu_f(b); }
+        w[j] = pack_bf2(a * sc, b * sc);
+      }
+      x = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    *reinterpret_cast<uint4*>(s) = x;
+  }
+};
+template <> struct Chunk<float> {
+  static constexpr int E = 4;
+  float4 v;
+  __device__ __forceinline__ void ld(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void zero_if(bool z) { if (z) v = make_float4(0.f, 0.f, 0.f, 0.f); }
+  template <bool GELU> __device__ __forceinline__ void st(__bf16* s, float sc, bool) const {
+    float4 x = v;
+    if (GELU) { x.x = gelu_f(x.x); x.y = gelu_f(x.y); x.z = gelu_f(x.z); x.w = gelu_f(x.w); }
+    *reinterpret_cast<uint2*>(s) = make_uint2(pack_bf2(x.x * sc, x.y * sc), pack_bf2(x.z * sc, x.w * sc));
+  }
+};
+
+// [R rows][BK] tile of a K-contiguous operand -> LDS [R][BK + 8]
+template <typename ST, int R, int BK, bool GELU> struct KcStage {
+  static constexpr int E = Chunk<ST>::E, CPR = BK / E, RPP = 256 / CPR, NP = R / RPP, LD = BK + 8;
+  static_assert(R % RPP == 0, "tile rows must be a multiple of the rows covered per pass");
+  const ST* base[NP];
+  Chunk<ST> c[NP];
+  uint32_t rowok;
+  int kq, r0;
+  __device__ __forceinline__ void init(const void* p, int64_t ld, int row0, int rmax, int tid) {
+    r0 = tid / CPR; kq = E * (tid % CPR); rowok = 0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int row = row0 + r0 + RPP * q;
+      if (row < rmax) rowok |= 1u << q;
+      base[q] = static_cast<const ST*>(p) + (int64_t)min(row, rmax - 1) * ld;
+    }
+  }
+  __device__ __forceinline__ void load(int k0, int kend) {
+    const bool kok = k0 + kq < kend;
+    const int ko = kok ? k0 + kq : 0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) c[q].ld(base[q] + ko);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) c[q].zero_if(!kok || !((rowok >> q) & 1));
+  }
+  __device__ __forceinline__ void store(__bf16* s) const {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) c[q].template st<GELU>(s + (r0 + RPP * q) * LD + kq, 1.f, false);
+  }
+};
+
+// [KT k-rows][R columns] tile of a row-contiguous operand -> LDS [KT][R + 32] (as it lies)
+template <typename ST, int R, int KT, bool GELU> struct TrStage {
+  static constexpr int E = Chunk<ST>::E, CPR = R / E, NCH = KT * CPR, NP = NCH / 256, LD = R + 32;
+  static_assert(NCH % 256 == 0, "tile must be a multiple of 256 chunks");
+  const ST* base[NP];
+  Chunk<ST> c[NP];
+  uint32_t colok;
+  int64_t ld;
+  __device__ __forceinline__ void init(const void* p, int64_t ld_, int c0, int cmax, int tid) {
+    ld = ld_; colok = 0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int col = c0 + E * ((tid + 256 * q) % CPR);
+      if (col < cmax) colok |= 1u << q;                    // cmax is a multiple of E (checked on the host)
+      base[q] = static_cast<const ST*>(p) + min(col, cmax - E);
+    }
+  }
+  __device__ __forceinline__ void load(int k0, int kend, int tid) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int k = k0 + (tid + 256 * q) / CPR;
+      c[q].ld(base[q] + (int64_t)min(k, kend - 1) * ld);
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int k = k0 + (tid + 256 * q) / CPR;
+      c[q].zero_if(k >= kend || !((colok >> q) & 1));
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* s, const float* kscale, int kps, int k0, int tid) const {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int ch = tid + 256 * q, kr = ch / CPR;
+      const float sc = kscale ? kscale[(k0 + kr) / kps] : 1.f;
+      c[q].template st<GELU>(s + kr * LD + E * (ch % CPR), sc, kscale != nullptr);
+    }
+  }
+};
+
+// XCD-aware tile order (speed only): workgroups that re-read one activation slab get ids equal mod 8 (same XCD L2)
+__device__ __forceinline__ bool tile_of_block(int tiles_n, int tiles_m, int ksplit, int& bx, int& by, int& bz) {
+  const int L = blockIdx.x, j = L & 7, sq = L >> 3;
+  if (ksplit > 1) {
+    const int tiles = tiles_n * tiles_m, t = sq % tiles;
+    bz = (sq / tiles) * 8 + j; bx = t % tiles_n; by = t / tiles_n;
+    return bz < ksplit;
+  }
+  bz = 0; bx = sq % tiles_n; by = (sq / tiles_n) * 8 + j;
+  return by < tiles_m;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemm g, const bool vec_ok, const int tiles_n, const int tiles_m) {
+  constexpr int BK = 64, BM = WM * TM * 32, BN = WN * TN * 32, LDA = BK + 8;
+  constexpr int LDB = B_TR ? BN + 32 : BK + 8, BSZ = B_TR ? BK * LDB : BN * LDB;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);          // [2][BM][LDA]
+  __bf16* Bs = As + 2 * BM * LDA;                            // [2][BSZ]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+  int bx, by, bz;
+  if (!tile_of_block(tiles_n, tiles_m, 1, bx, by, bz)) return;
+  const int m0 = by * BM, n0 = bx * BN, K = g.K;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  KcStage<AT, BM, BK, A_GELU> sa;
+  sa.init(g.A, g.lda, m0, g.M, tid);
+  KcStage<BT, BN, BK, false> sbk;
+  TrStage<BT, BN, BK, false> sbt;
+  if constexpr (B_TR) sbt.init(g.B, g.ldb, n0, g.N, tid); else sbk.init(g.B, g.ldb, n0, g.N, tid);
+
+  sa.load(0, K);
+  if constexpr (B_TR) sbt.load(0, K, tid); else sbk.load(0, K);
+  sa.store(As);
+  if constexpr (B_TR) sbt.store(Bs, nullptr, 1, 0, tid); else sbk.store(Bs);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const bool more = k0 + BK < K;
+    if (more) {
+      sa.load(k0 + BK, K);
+      if constexpr (B_TR) sbt.load(k0 + BK, K, tid); else sbk.load(k0 + BK, K);
+    }
+    const __bf16* Ab = As + buf * BM * LDA + ((wm * TM) * 32 + r) * LDA;
+    const __bf16* Bb = Bs + buf * BSZ;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDA + 16 * ks + 8 * h);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (B_TR) b[j] = tr_frag(Bb, LDB, (wn * TN + j) * 32, ks, lane);
+        else b[j] = *reinterpret_cast<const bf16x8*>(Bb + ((wn * TN + j) * 32 + r) * LDB + 16 * ks + 8 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      sa.store(As + (buf ^ 1) * BM * LDA);
+      if constexpr (B_TR) sbt.store(Bs + (buf ^ 1) * BSZ, nullptr, 1, k0 + BK, tid); else sbk.store(Bs + (buf ^ 1) * BSZ);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // epilogue: accumulators -> LDS (fp32 tile) -> coalesced 16-byte rows
+  constexpr int LDC = BN + 4;
+  float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        Cs[((wm * TM + i) * 32 + mma32_row(e, h)) * LDC + (wn * TN + j) * 32 + r] = acc[i][j][e];
+  __syncthreads();
+  constexpr int TPRW = BN / 4, RPP = 256 / TPRW;
+  const int c4 = tid % TPRW, n = n0 + 4 * c4;
+  const bool full = vec_ok && n + 3 < g.N;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (full && g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + n);
+  for (int rr = tid / TPRW; rr < BM; rr += RPP) {
+    const int m = m0 + rr;
+    if (m >= g.M) break;
+    float4 v = *reinterpret_cast<const float4*>(Cs + rr * LDC + 4 * c4);
+    if (full) {
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      if (g.rowscale) {
+        const float sc = g.rowscale[m / g.rows_per_scale];
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      }
+      if (g.gaux) {
+        const float4 a = g.gaux_bf16 ? IO<__bf16>::ld4(static_cast<const __bf16*>(g.gaux) + (int64_t)m * g.ldg + n)
+                                     : IO<float>::ld4(static_cast<const float*>(g.gaux) + (int64_t)m * g.ldg + n);
+        v.x *= gelu_grad_f(a.x); v.y *= gelu_grad_f(a.y); v.z *= gelu_grad_f(a.z); v.w *= gelu_grad_f(a.w);
+      }
+      if (g.res) {
+        const float4 a = *reinterpret_cast<const float4*>(g.res + (int64_t)m * g.ldr + n);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      if (g.c_bf16) IO<__bf16>::st4(static_cast<__bf16*>(g.C) + (int64_t)m * g.ldc + n, v);
+      else IO<float>::st4(static_cast<float*>(g.C) + (int64_t)m * g.ldc + n, v);
+    } else {
+      const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nn = n + q;
+        if (nn >= g.N) continue;
+        float val = e4[q];
+        if (g.bias) val += g.bias[nn];
+        if (g.rowscale) val *= g.rowscale[m / g.rows_per_scale];
+        if (g.gaux) val *= gelu_grad_f(g.gaux_bf16 ? (float)static_cast<const __bf16*>(g.gaux)[(int64_t)m * g.ldg + nn]
+                                                   : static_cast<const float*>(g.gaux)[(int64_t)m * g.ldg + nn]);
+        if (g.res) val += g.res[(int64_t)m * g.ldr + nn];
+        if (g.c_bf16) static_cast<__bf16*>(g.C)[(int64_t)m * g.ldc + nn] = (__bf16)val;
+        else static_cast<float*>(g.C)[(int64_t)m * g.ldc + nn] = val;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int TBK = 32;                                    // k rows per tile of the weight-gradient kernel
+
+template <typename AT, typename BT, bool B_GELU, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int klen, const int tiles_n, const int tiles_m,
+                                                      const int ksplit) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 32, LDB = BN + 32;
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][TBK * LDA];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TBK * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  int bx, by, bz;
+  {
+    const int L = blockIdx.x, j = L & 7, sq = L >> 3, tiles = tiles_n * tiles_m, t = sq % tiles;
+    bz = (sq / tiles) * 8 + j; bx = t % tiles_n; by = t / tiles_n;
+    if (bz >= ksplit) return;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * klen, kend = min(g.K, kbeg + klen);
+  const bool do_bias = g.b_ones && bx == 0;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float bsum = 0.f;
+
+  TrStage<AT, BM, TBK, false> sa;
+  TrStage<BT, BN, TBK, B_GELU> sb;
+  sa.init(g.A, g.lda, m0, g.M, tid);
+  sb.init(g.B, g.ldb, n0, g.N, tid);
+  sa.load(kbeg, kend, tid);
+  sb.load(kbeg, kend, tid);
+  sa.store(As[0], g.kscale, g.k_per_scale, kbeg, tid);
+  sb.store(Bs[0], nullptr, 1, kbeg, tid);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += TBK) {
+    const bool more = k0 + TBK < kend;
+    if (more) {
+      sa.load(k0 + TBK, kend, tid);
+      sb.load(k0 + TBK, kend, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < TBK / 16; ++ks) {
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = tr_frag(As[buf], LDA, (wm * TM + i) * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = tr_frag(Bs[buf], LDB, (wn * TN + j) * 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_bias && tid < BM) {
+#pragma unroll 8
+      for (int kr = 0; kr < TBK; ++kr) bsum += (float)As[buf][kr * LDA + tid];
+    }
+    if (more) {
+      sa.store(As[buf ^ 1], g.kscale, g.k_per_scale, k0 + TBK, tid);
+      sb.store(Bs[buf ^ 1], nullptr, 1, k0 + TBK, tid);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* C = static_cast<float*>(g.C);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + (wm * TM + i) * 32 + mma32_row(e, h);
+        if (m < g.M && n < g.N) atomicAdd(C + (int64_t)m * g.ldc + n, acc[i][j][e]);
+      }
+    }
+  if (do_bias && tid < BM && m0 + tid < g.M) atomicAdd(g.C2 + m0 + tid, bsum);
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN>
+int launch_nt(const WmGemm& g, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 64;
+  constexpr size_t bsz = B_TR ? BK * (BN + 32) : BN * (BK + 8);
+  constexpr size_t stage = 2 * 2 * (BM * (BK + 8) + bsz), ctile = sizeof(float) * BM * (BN + 4);
+  constexpr size_t smem = stage > ctile ? stage : ctile;
+  static bool attr = false;
+  if (!attr) {
+    if (smem > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  const bool vec_ok = al16(g.C) && !(g.ldc & 7) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && !(g.ldr & 3))) &&
+                      (!g.gaux || (al16(g.gaux) && !(g.ldg & 7)));
+  hipLaunchKernelGGL((gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN>), dim3(8 * ((tiles_m + 7) / 8) * tiles_n), dim3(256),
+                     smem, st, g, vec_ok, tiles_n, tiles_m);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+template <typename AT, typename BT, bool B_TR, bool A_GELU>
+int dispatch_nt(const WmGemm& g, hipStream_t st) {
+  const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  const int64_t t12864 = (int64_t)((g.M + 127) / 128) * ((g.N + 63) / 64);
+  if (g.N <= 32) return launch_nt<AT, BT, B_TR, A_GELU, 4, 1, 2, 1>(g, st);          // 256 x 32
+  if (g.N > 64 && t128 >= 384) return launch_nt<AT, BT, B_TR, A_GELU, 2, 2, 2, 2>(g, st);   // 128 x 128
+  if (t12864 >= 384 || g.M >= 32768) return launch_nt<AT, BT, B_TR, A_GELU, 2, 2, 2, 1>(g, st);  // 128 x 64
+  return launch_nt<AT, BT, B_TR, A_GELU, 2, 2, 1, 1>(g, st);                           // 64 x 64
+}
+
+template <typename AT, typename BT, bool B_GELU, int TM, int TN>
+int launch_tn(const WmGemm& g, hipStream_t st) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
+  int ksplit = g.ksplit > 0 ? g.ksplit : (768 + tiles - 1) / tiles;
+  const int maxs = (g.K + 255) / 256;
+  if (ksplit > maxs) ksplit = maxs;
+  if (ksplit < 1) ksplit = 1;
+  int klen = (g.K + ksplit - 1) / ksplit;
+  klen = (klen + TBK - 1) / TBK * TBK;
+  ksplit = (g.K + klen - 1) / klen;
+  hipLaunchKernelGGL((gemm_tn_kernel<AT, BT, B_GELU, TM, TN>), dim3(8 * ((ksplit + 7) / 8) * tiles), dim3(256), 0, st, g, klen,
+                     tiles_n, tiles_m, ksplit);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+template <typename AT, typename BT, bool B_GELU>
+int dispatch_tn(const WmGemm& g, hipStream_t st) {
+  if (g.M > 64 && g.N > 64) return launch_tn<AT, BT, B_GELU, 2, 2>(g, st);
+  if (g.M > 64) return launch_tn<AT, BT, B_GELU, 2, 1>(g, st);
+  return launch_tn<AT, BT, B_GELU, 1, 1>(g, st);
+}
+
+}  // namespace
+
+// Returns -1 when the launch does not fit the fast kernels (caller falls back to the generic kernel of gemm.hip).
+int wm_gemm_fast_bf16(const WmGemm& g, hipStream_t st) {
+  if (g.mode != 1 || getenv("WM_NO_FAST")) return -1;
+  const int ea = g.a_bf16 ? 8 : 4, eb = g.b_bf16 ? 8 : 4;
+  if (!g.a_kc && !g.b_kc && g.atomic_out && !g.a_op && !g.c_bf16) {          // weight gradient
+    if ((g.M % ea) || (g.N % eb) || (g.lda % ea) || (g.ldb % eb) || g.M < ea || g.N < eb) return -1;
+    if (g.b_op) {
+      if (g.a_bf16 && g.b_bf16) return dispatch_tn<__bf16, __bf16, true>(g, st);
+      if (g.a_bf16) return dispatch_tn<__bf16, float, true>(g, st);
+      if (g.b_bf16) return dispatch_tn<float, __bf16, true>(g, st);
+      return dispatch_tn<float, float, true>(g, st);
+    }
+    if (g.a_bf16 && g.b_bf16) return dispatch_tn<__bf16, __bf16, false>(g, st);
+    if (g.a_bf16) return dispatch_tn<__bf16, float, false>(g, st);
+    if (g.b_bf16) return dispatch_tn<float, __bf16, false>(g, st);
+    return dispatch_tn<float, float, false>(g, st);
+  }
+  if (g.a_kc && !g.atomic_out && !g.b_ones && !g.b_op && !g.kscale && g.b_bf16 && (g.K % 8) == 0 && g.K >= 8 &&
+      (g.lda % ea) == 0) {
+    if (g.b_kc) {                                                             // forward: B = [N, K] weight copy
+      if (g.ldb % 8) return -1;
+      if (g.a_op) return g.a_bf16 ? dispatch_nt<__bf16, __bf16, false, true>(g, st) : dispatch_nt<float, __bf16, false, true>(g, st);
+      return g.a_bf16 ? dispatch_nt<__bf16, __bf16, false, false>(g, st) : dispatch_nt<float, __bf16, false, false>(g, st);
+    }
+    if (g.a_op || (g.N % 8) || (g.ldb % 8) || g.N < 8) return -1;             // dX: B = [K, N] weight copy
+    return g.a_bf16 ? dispatch_nt<__bf16, __bf16, true, false>(g, st) : dispatch_nt<float, __bf16, true, false>(g, st);
+  }
+  return -1;
+}
