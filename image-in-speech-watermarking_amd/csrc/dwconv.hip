@@ -31,7 +31,7 @@ __device__ __forceinline__ void load_halo_tile(float* tile, const ST* __restrict
 template <typename ST>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ST* __restrict__ h1, const float* __restrict__ w,
                                                          const float* __restrict__ bias, ST* __restrict__ h2,
-                                                         int B, int hw, int Ch) {
+                                                         ST* __restrict__ a2, int B, int hw, int Ch) {
   __shared__ __attribute__((aligned(16))) float tile[HP * HP * TC];
   const int tid = threadIdx.x, nt = hw / TP;
   const int t = blockIdx.x, b = t / (nt * nt), tr = t - b * nt * nt, ty = tr / nt, tx = tr - ty * nt;
@@ -59,7 +59,11 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ST* __restrict__ 
         o[2] += wr[2][dy * 3 + dx] * a.z; o[3] += wr[3][dy * 3 + dx] * a.w;
       }
     const int gy = ty * TP + py, gx = tx * TP + px;
-    IO<ST>::st4(h2 + (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4, make_float4(o[0], o[1], o[2], o[3]));
+    const int64_t off = (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4;
+    IO<ST>::st4(h2 + off, make_float4(o[0], o[1], o[2], o[3]));
+    // second GELU materialised once here: evaluating it while the consumer GEMM stages its A operand repeats it for
+    // every column tile and made linear2 / dW2 VALU-bound
+    if (a2) IO<ST>::st4(a2 + off, make_float4(gelu_f(o[0]), gelu_f(o[1]), gelu_f(o[2]), gelu_f(o[3])));
   }
 }
 
@@ -142,17 +146,17 @@ bool ok(int B, int hw, int Ch) { return B > 0 && hw >= 8 && (hw & 7) == 0 && Ch 
 
 }  // namespace
 
-extern "C" int wm_dwconv_fwd(const void* h1, const float* w, const float* b, void* h2, int32_t io_bf16, int32_t B,
-                             int32_t hw, int32_t Ch, void* stream) {
+extern "C" int wm_dwconv_fwd(const void* h1, const float* w, const float* b, void* h2, void* a2, int32_t io_bf16,
+                             int32_t B, int32_t hw, int32_t Ch, void* stream) {
   if (!h1 || !w || !b || !h2 || !ok(B, hw, Ch)) return WM_EINVAL;
   const int nt = hw / TP;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (io_bf16)
     hipLaunchKernelGGL(dwconv_fwd_kernel<__bf16>, dim3(B * nt * nt, Ch / TC), dim3(256), 0, st,
-                       static_cast<const __bf16*>(h1), w, b, static_cast<__bf16*>(h2), B, hw, Ch);
+                       static_cast<const __bf16*>(h1), w, b, static_cast<__bf16*>(h2), static_cast<__bf16*>(a2), B, hw, Ch);
   else
     hipLaunchKernelGGL(dwconv_fwd_kernel<float>, dim3(B * nt * nt, Ch / TC), dim3(256), 0, st,
-                       static_cast<const float*>(h1), w, b, static_cast<float*>(h2), B, hw, Ch);
+                       static_cast<const float*>(h1), w, b, static_cast<float*>(h2), static_cast<float*>(a2), B, hw, Ch);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

@@ -374,22 +374,22 @@ class UformerAudio(nn.Module):
         ops.layernorm_fwd(x1, P[pre + "norm2.weight"], P[pre + "norm2.bias"], None, xn2, mean2, rstd2, hw, 0)
         h1 = H(dev, M, 4 * C)
         ops.linear_fwd(xn2, W(pre + "mlp.linear1.0.weight"), P[pre + "mlp.linear1.0.bias"], h1, mode)
-        h2 = H(dev, M, 4 * C)
-        ops.dwconv_fwd(h1, P[pre + "mlp.dwconv.0.weight"], P[pre + "mlp.dwconv.0.bias"], h2, B, hw, 4 * C)
+        h2, a2 = H(dev, M, 4 * C), H(dev, M, 4 * C)
+        ops.dwconv_fwd(h1, P[pre + "mlp.dwconv.0.weight"], P[pre + "mlp.dwconv.0.bias"], h2, B, hw, 4 * C, a2=a2)
         x2 = _E(dev, M, C)
-        ops.linear_fwd(h2, W(pre + "mlp.linear2.0.weight"), P[pre + "mlp.linear2.0.bias"], x2, mode, a_op=1, res=x1,
+        ops.linear_fwd(a2, W(pre + "mlp.linear2.0.weight"), P[pre + "mlp.linear2.0.bias"], x2, mode, res=x1,
                        rowscale=s2, rows_per_scale=N)
-        return x2, (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2)
+        return x2, (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2)
 
     def _block_bwd(self, sv, dy):
-        (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2) = sv
+        (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2) = sv
         P, G, dev, mode = self._views, self._gviews, x.device, self._mode()
         M, N = x.shape[0], hw * hw
         # LeFF
         H, W = self._H, self._W
         dh2 = H(dev, M, 4 * C)
         ops.linear_bwd_input(dy, W(pre + "mlp.linear2.0.weight"), dh2, mode, rowscale=s2, rows_per_scale=N, gaux=h2)
-        ops.linear_bwd_weight(dy, h2, G[pre + "mlp.linear2.0.weight"], G[pre + "mlp.linear2.0.bias"], mode, x_op=1,
+        ops.linear_bwd_weight(dy, a2, G[pre + "mlp.linear2.0.weight"], G[pre + "mlp.linear2.0.bias"], mode,
                               kscale=s2, k_per_scale=N)
         dh1 = H(dev, M, 4 * C)
         ops.dwconv_bwd(h1, dh2, P[pre + "mlp.dwconv.0.weight"], dh1, G[pre + "mlp.dwconv.0.weight"],

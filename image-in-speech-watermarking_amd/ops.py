@@ -86,10 +86,10 @@ def winattn_bwd(qkv, table, dout, dqkv, dtable, B, hw, Cc, shift, mode):
                              _stream()), "wm_winattn_bwd")
 
 
-def dwconv_fwd(h1, w, b, h2, B, hw, Ch):
-    if _bf(h1) != _bf(h2):
-        raise ValueError("dwconv: h1 and h2 must share a storage type")
-    check(lib.wm_dwconv_fwd(ptr(h1), ptr(w), ptr(b), ptr(h2), _bf(h1), B, hw, Ch, _stream()), "wm_dwconv_fwd")
+def dwconv_fwd(h1, w, b, h2, B, hw, Ch, a2=None):
+    if _bf(h1) != _bf(h2) or (a2 is not None and _bf(a2) != _bf(h2)):
+        raise ValueError("dwconv: h1, h2 and a2 must share a storage type")
+    check(lib.wm_dwconv_fwd(ptr(h1), ptr(w), ptr(b), ptr(h2), ptr(a2), _bf(h1), B, hw, Ch, _stream()), "wm_dwconv_fwd")
 
 
 def dwconv_bwd(h1, dh2, w, dh1, dw, db, B, hw, Ch):

@@ -19,11 +19,11 @@ def _gemm_cost(a):
     A, B, C, M, N, K = a[:6]
     kw = a[-1]
     flops = 2.0 * M * N * K
-    byts = 4.0 * (M * K + N * K + M * N)
+    byts = A.element_size() * M * K + B.element_size() * N * K + C.element_size() * M * N
     if kw.get("res") is not None:
         byts += 4.0 * M * N
     if kw.get("gaux") is not None:
-        byts += 4.0 * M * N
+        byts += kw["gaux"].element_size() * M * N
     return flops, byts
 
 
@@ -34,12 +34,12 @@ def _attn_cost(B, hw, C, products):
 
 COST = {
     "gemm": lambda *a, **k: _gemm_cost(a + (k,)),
-    "winattn_fwd": lambda qkv, t, o, B, hw, C, sh, mode: (_attn_cost(B, hw, C, 2), 4.0 * B * hw * hw * 4 * C),
-    "winattn_bwd": lambda qkv, t, do, dq, dt, B, hw, C, sh, mode: (_attn_cost(B, hw, C, 6), 4.0 * B * hw * hw * 7 * C),
-    "dwconv_fwd": lambda h1, w, b, h2, B, hw, Ch: (18.0 * B * hw * hw * Ch, 8.0 * B * hw * hw * Ch),
-    "dwconv_bwd": lambda h1, d, w, dh, dw, db, B, hw, Ch: (54.0 * B * hw * hw * Ch, 16.0 * B * hw * hw * Ch),
-    "layernorm_fwd": lambda x, *a: (8.0 * x.numel(), 8.0 * x.numel()),
-    "layernorm_bwd": lambda dy, x, *a: (16.0 * x.numel(), 16.0 * x.numel()),
+    "winattn_fwd": lambda qkv, t, o, B, hw, C, sh, mode: (_attn_cost(B, hw, C, 2), qkv.element_size() * B * hw * hw * 4.0 * C),
+    "winattn_bwd": lambda qkv, t, do, dq, dt, B, hw, C, sh, mode: (_attn_cost(B, hw, C, 6), qkv.element_size() * B * hw * hw * 7.0 * C),
+    "dwconv_fwd": lambda h1, w, b, h2, B, hw, Ch, a2=None: (18.0 * B * hw * hw * Ch, (3.0 if a2 is not None else 2.0) * h1.element_size() * B * hw * hw * Ch),
+    "dwconv_bwd": lambda h1, d, w, dh, dw, db, B, hw, Ch: (54.0 * B * hw * hw * Ch, 3.0 * h1.element_size() * B * hw * hw * Ch),
+    "layernorm_fwd": lambda x, g, b, m, y, *a: (8.0 * x.numel(), (4.0 + y.element_size()) * x.numel()),
+    "layernorm_bwd": lambda dy, x, *a: (16.0 * x.numel(), (12.0 + dy.element_size()) * x.numel()),
     "im2col": lambda x, cols, *a: (0.0, 4.0 * (x.numel() + cols.numel())),
     "col2im": lambda dc, dx, *a: (0.0, 4.0 * (dx.numel() + dc.numel())),
     "pixel_shuffle": lambda y4, *a: (0.0, 8.0 * y4.numel()),

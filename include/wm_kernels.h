@@ -69,9 +69,10 @@ int wm_winattn_bwd(const void* qkv, const float* bias_table, const void* dout, v
                    int32_t mode, void* stream);
 
 /* ---- LeFF depthwise 3x3 on token-major [B,hw,hw,Ch] — model.py:703-709.  Input is the
- * PRE-GELU linear1 output; GELU is applied while staging.  Output is pre-GELU too.            */
-int wm_dwconv_fwd(const void* h1, const float* w, const float* b, void* h2, int32_t io_bf16, int32_t B, int32_t hw,
-                  int32_t Ch, void* stream);
+ * PRE-GELU linear1 output; GELU is applied while staging.  Outputs: h2 (pre-GELU, kept for gelu' in
+ * backward) and optionally a2 = GELU(h2), the A operand of linear2.                            */
+int wm_dwconv_fwd(const void* h1, const float* w, const float* b, void* h2, void* a2 /* gelu(h2) or NULL */,
+                  int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream);
 /* dh1 = gelu'(h1) * conv^T(dh2);  dw[Ch,9], db[Ch] accumulated */
 int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, void* dh1, float* dw, float* db,
                   int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream);

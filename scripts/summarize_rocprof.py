@@ -16,8 +16,24 @@ import sys
 
 
 def short(name):
+    """Readable kernel name; itanium-mangled template instances are decoded far enough to tell them apart."""
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"void ", "", name)
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)I(.*?)EEv", name)
+    if m:
+        toks, rest = [], m.group(2)
+        while rest:
+            for pat, fn in ((r"DF16b", lambda g: "bf16"), (r"f", lambda g: "f32"), (r"Lb([01])E", lambda g: g.group(1)),
+                            (r"Li(\d+)E", lambda g: g.group(1))):
+                g = re.match(pat, rest)
+                if g:
+                    toks.append(fn(g))
+                    rest = rest[g.end():]
+                    break
+            else:
+                toks.append(rest)
+                break
+        return f"{m.group(1)}<{','.join(toks)}>"
     return name[:110]
 
 

@@ -184,8 +184,10 @@ def test_dwconv_fwd_bwd(wm, hw, Ch):
     ref.backward(g)
     h2 = torch.empty(B, hw, hw, Ch, device="cuda")
     hd, wd = dev(h1.detach()), dev(w.detach())
-    ops.dwconv_fwd(hd, wd, dev(b.detach()), h2, B, hw, Ch)
+    a2 = torch.empty_like(h2)
+    ops.dwconv_fwd(hd, wd, dev(b.detach()), h2, B, hw, Ch, a2=a2)
     assert_close(h2, ref.detach(), 1e-5, "dwconv fwd")
+    assert_close(a2, F.gelu(ref.detach()), 1e-5, "dwconv fwd gelu output")
     dh1 = torch.empty_like(hd)
     dwg, dbg = torch.zeros(Ch, 9, device="cuda"), torch.zeros(Ch, device="cuda")
     ops.dwconv_bwd(hd, dev(g), wd, dh1, dwg, dbg, B, hw, Ch)
