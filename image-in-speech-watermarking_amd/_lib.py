@@ -24,7 +24,8 @@ class WmGemm(C.Structure):
                 ("gaux", c_f), ("ldg", c_i64),
                 ("b_ones", c_i32), ("C2", c_f),
                 ("atomic_out", c_i32), ("ksplit", c_i32), ("mode", c_i32),
-                ("a_bf16", c_i32), ("b_bf16", c_i32), ("c_bf16", c_i32), ("gaux_bf16", c_i32)]
+                ("a_bf16", c_i32), ("b_bf16", c_i32), ("c_bf16", c_i32), ("gaux_bf16", c_i32),
+                ("gaux_raw", c_i32)]
 
 
 class WmConv(C.Structure):
@@ -44,7 +45,7 @@ _SIGS = {
     "wm_layernorm_bwd": [c_f, c_i32] + [c_f] * 9 + [c_i64, c_i32, c_i32, c_i32, c_f],
     "wm_winattn_fwd": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_winattn_bwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
-    "wm_dwconv_fwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_dwconv_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_dwconv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_im2col_4x4s2": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_col2im_4x4s2": [c_f, c_i32, c_f, c_i32, c_i32, c_i32, c_f],

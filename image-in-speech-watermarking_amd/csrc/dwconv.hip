@@ -31,7 +31,8 @@ __device__ __forceinline__ void load_halo_tile(float* tile, const ST* __restrict
 template <typename ST>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ST* __restrict__ h1, const float* __restrict__ w,
                                                          const float* __restrict__ bias, ST* __restrict__ h2,
-                                                         ST* __restrict__ a2, int B, int hw, int Ch) {
+                                                         ST* __restrict__ a2, ST* __restrict__ g2, int B, int hw,
+                                                         int Ch) {
   __shared__ __attribute__((aligned(16))) float tile[HP * HP * TC];
   const int tid = threadIdx.x, nt = hw / TP;
   const int t = blockIdx.x, b = t / (nt * nt), tr = t - b * nt * nt, ty = tr / nt, tx = tr - ty * nt;
@@ -60,10 +61,23 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ST* __restrict__ 
       }
     const int gy = ty * TP + py, gx = tx * TP + px;
     const int64_t off = (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4;
-    IO<ST>::st4(h2 + off, make_float4(o[0], o[1], o[2], o[3]));
-    // second GELU materialised once here: evaluating it while the consumer GEMM stages its A operand repeats it for
-    // every column tile and made linear2 / dW2 VALU-bound
-    if (a2) IO<ST>::st4(a2 + off, make_float4(gelu_f(o[0]), gelu_f(o[1]), gelu_f(o[2]), gelu_f(o[3])));
+    if (h2) IO<ST>::st4(h2 + off, make_float4(o[0], o[1], o[2], o[3]));
+    // second GELU and its derivative are materialised once here, from one shared exp(): evaluating them inside the
+    // consumer GEMMs (A-operand staging of linear2 / dW2, epilogue of d_h2) repeated them per column tile and made
+    // those launches VALU-bound
+    if (a2 || g2) {
+      float av[4], gv[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const float e = __expf(-0.5f * o[cc] * o[cc]);
+        const float t = phi_tail_f(o[cc], e);
+        const float cdf = o[cc] >= 0.f ? 1.0f - t : t;
+        av[cc] = o[cc] * cdf;
+        gv[cc] = cdf + o[cc] * 0.39894228040143268f * e;
+      }
+      if (a2) IO<ST>::st4(a2 + off, make_float4(av[0], av[1], av[2], av[3]));
+      if (g2) IO<ST>::st4(g2 + off, make_float4(gv[0], gv[1], gv[2], gv[3]));
+    }
   }
 }
 
@@ -146,17 +160,17 @@ bool ok(int B, int hw, int Ch) { return B > 0 && hw >= 8 && (hw & 7) == 0 && Ch 
 
 }  // namespace
 
-extern "C" int wm_dwconv_fwd(const void* h1, const float* w, const float* b, void* h2, void* a2, int32_t io_bf16,
+extern "C" int wm_dwconv_fwd(const void* h1, const float* w, const float* b, void* h2, void* a2, void* g2, int32_t io_bf16,
                              int32_t B, int32_t hw, int32_t Ch, void* stream) {
-  if (!h1 || !w || !b || !h2 || !ok(B, hw, Ch)) return WM_EINVAL;
+  if (!h1 || !w || !b || (!h2 && !a2 && !g2) || !ok(B, hw, Ch)) return WM_EINVAL;
   const int nt = hw / TP;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (io_bf16)
     hipLaunchKernelGGL(dwconv_fwd_kernel<__bf16>, dim3(B * nt * nt, Ch / TC), dim3(256), 0, st,
-                       static_cast<const __bf16*>(h1), w, b, static_cast<__bf16*>(h2), static_cast<__bf16*>(a2), B, hw, Ch);
+                       static_cast<const __bf16*>(h1), w, b, static_cast<__bf16*>(h2), static_cast<__bf16*>(a2), static_cast<__bf16*>(g2), B, hw, Ch);
   else
     hipLaunchKernelGGL(dwconv_fwd_kernel<float>, dim3(B * nt * nt, Ch / TC), dim3(256), 0, st,
-                       static_cast<const float*>(h1), w, b, static_cast<float*>(h2), static_cast<float*>(a2), B, hw, Ch);
+                       static_cast<const float*>(h1), w, b, static_cast<float*>(h2), static_cast<float*>(a2), static_cast<float*>(g2), B, hw, Ch);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

@@ -453,7 +453,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int kle
         } else {
           a = *reinterpret_cast<const float4*>(static_cast<const float*>(g.gaux) + (int64_t)m * g.ldg + n);
         }
-        v.x *= gelu_grad_f(a.x); v.y *= gelu_grad_f(a.y); v.z *= gelu_grad_f(a.z); v.w *= gelu_grad_f(a.w);
+        if (g.gaux_raw) { v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w; }
+        else { v.x *= gelu_grad_f(a.x); v.y *= gelu_grad_f(a.y); v.z *= gelu_grad_f(a.z); v.w *= gelu_grad_f(a.w); }
       }
       if (g.res) {
         const float4 a = *reinterpret_cast<const float4*>(g.res + (int64_t)m * g.ldr + n);
@@ -479,8 +480,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const WmGemm g, const int kle
         if (nn < g.N) {
           if (g.bias) val += g.bias[nn];
           if (g.rowscale) val *= g.rowscale[m / g.rows_per_scale];
-          if (g.gaux) val *= gelu_grad_f(g.gaux_bf16 ? (float)reinterpret_cast<const __bf16*>(g.gaux)[(int64_t)m * g.ldg + nn]
-                                                     : static_cast<const float*>(g.gaux)[(int64_t)m * g.ldg + nn]);
+          if (g.gaux) {
+            const float av = g.gaux_bf16 ? (float)reinterpret_cast<const __bf16*>(g.gaux)[(int64_t)m * g.ldg + nn]
+                                         : static_cast<const float*>(g.gaux)[(int64_t)m * g.ldg + nn];
+            val *= g.gaux_raw ? av : gelu_grad_f(av);
+          }
           if (g.res) val += g.res[(int64_t)m * g.ldr + nn];
           if (g.c_bf16) {
             reinterpret_cast<__bf16*>(g.C)[(int64_t)m * g.ldc + nn] = (__bf16)val;

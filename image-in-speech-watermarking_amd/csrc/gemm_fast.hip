@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemm g, const bool
       if (g.gaux) {
         const float4 a = g.gaux_bf16 ? IO<__bf16>::ld4(static_cast<const __bf16*>(g.gaux) + (int64_t)m * g.ldg + n)
                                      : IO<float>::ld4(static_cast<const float*>(g.gaux) + (int64_t)m * g.ldg + n);
-        v.x *= gelu_grad_f(a.x); v.y *= gelu_grad_f(a.y); v.z *= gelu_grad_f(a.z); v.w *= gelu_grad_f(a.w);
+        if (g.gaux_raw) { v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w; }
+        else { v.x *= gelu_grad_f(a.x); v.y *= gelu_grad_f(a.y); v.z *= gelu_grad_f(a.z); v.w *= gelu_grad_f(a.w); }
       }
       if (g.res) {
         const float4 a = *reinterpret_cast<const float4*>(g.res + (int64_t)m * g.ldr + n);
@@ -254,8 +255,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemm g, const bool
         float val = e4[q];
         if (g.bias) val += g.bias[nn];
         if (g.rowscale) val *= g.rowscale[m / g.rows_per_scale];
-        if (g.gaux) val *= gelu_grad_f(g.gaux_bf16 ? (float)static_cast<const __bf16*>(g.gaux)[(int64_t)m * g.ldg + nn]
-                                                   : static_cast<const float*>(g.gaux)[(int64_t)m * g.ldg + nn]);
+        if (g.gaux) {
+          const float av = g.gaux_bf16 ? (float)static_cast<const __bf16*>(g.gaux)[(int64_t)m * g.ldg + nn]
+                                       : static_cast<const float*>(g.gaux)[(int64_t)m * g.ldg + nn];
+          val *= g.gaux_raw ? av : gelu_grad_f(av);
+        }
         if (g.res) val += g.res[(int64_t)m * g.ldr + nn];
         if (g.c_bf16) static_cast<__bf16*>(g.C)[(int64_t)m * g.ldc + nn] = (__bf16)val;
         else static_cast<float*>(g.C)[(int64_t)m * g.ldc + nn] = val;

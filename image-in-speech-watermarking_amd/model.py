@@ -374,8 +374,8 @@ class UformerAudio(nn.Module):
         ops.layernorm_fwd(x1, P[pre + "norm2.weight"], P[pre + "norm2.bias"], None, xn2, mean2, rstd2, hw, 0)
         h1 = H(dev, M, 4 * C)
         ops.linear_fwd(xn2, W(pre + "mlp.linear1.0.weight"), P[pre + "mlp.linear1.0.bias"], h1, mode)
-        h2, a2 = H(dev, M, 4 * C), H(dev, M, 4 * C)
-        ops.dwconv_fwd(h1, P[pre + "mlp.dwconv.0.weight"], P[pre + "mlp.dwconv.0.bias"], h2, B, hw, 4 * C, a2=a2)
+        a2, h2 = H(dev, M, 4 * C), H(dev, M, 4 * C)       # h2 holds gelu'(dwconv output): all backward needs of it
+        ops.dwconv_fwd(h1, P[pre + "mlp.dwconv.0.weight"], P[pre + "mlp.dwconv.0.bias"], None, B, hw, 4 * C, a2=a2, g2=h2)
         x2 = _E(dev, M, C)
         ops.linear_fwd(a2, W(pre + "mlp.linear2.0.weight"), P[pre + "mlp.linear2.0.bias"], x2, mode, res=x1,
                        rowscale=s2, rows_per_scale=N)
@@ -388,7 +388,7 @@ class UformerAudio(nn.Module):
         # LeFF
         H, W = self._H, self._W
         dh2 = H(dev, M, 4 * C)
-        ops.linear_bwd_input(dy, W(pre + "mlp.linear2.0.weight"), dh2, mode, rowscale=s2, rows_per_scale=N, gaux=h2)
+        ops.linear_bwd_input(dy, W(pre + "mlp.linear2.0.weight"), dh2, mode, rowscale=s2, rows_per_scale=N, gaux=h2, gaux_raw=True)
         ops.linear_bwd_weight(dy, a2, G[pre + "mlp.linear2.0.weight"], G[pre + "mlp.linear2.0.bias"], mode,
                               kscale=s2, k_per_scale=N)
         dh1 = H(dev, M, 4 * C)

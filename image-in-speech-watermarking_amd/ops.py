@@ -30,10 +30,10 @@ def _bf(t):
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=1, b_kc=1, a_op=0, b_op=0, bias=None, res=None, ldr=0,
          rowscale=None, rows_per_scale=0, kscale=None, k_per_scale=0, gaux=None, ldg=0, b_ones=False, C2=None,
-         atomic_out=False, ksplit=0, mode=MODE_FP32):
+         atomic_out=False, ksplit=0, mode=MODE_FP32, gaux_raw=False):
     g = WmGemm(ptr(A), ptr(B), ptr(Cout), M, N, K, lda, ldb, ldc, a_kc, b_kc, a_op, b_op, ptr(bias), ptr(res), ldr,
                ptr(rowscale), rows_per_scale, ptr(kscale), k_per_scale, ptr(gaux), ldg, int(b_ones), ptr(C2),
-               int(atomic_out), ksplit, mode, _bf(A), _bf(B), _bf(Cout), _bf(gaux))
+               int(atomic_out), ksplit, mode, _bf(A), _bf(B), _bf(Cout), _bf(gaux), int(gaux_raw))
     check(lib.wm_gemm(C.byref(g), _stream()), f"wm_gemm(M={M},N={N},K={K})")
 
 
@@ -45,12 +45,12 @@ def linear_fwd(x, w, bias, out, mode, a_op=0, res=None, rowscale=None, rows_per_
          rows_per_scale=rows_per_scale, mode=mode)
 
 
-def linear_bwd_input(dy, w, dx, mode, rowscale=None, rows_per_scale=0, gaux=None):
-    """dx[M,K] = ((dy[M,N] @ w[N,K]) * rowscale) * gelu'(gaux)"""
+def linear_bwd_input(dy, w, dx, mode, rowscale=None, rows_per_scale=0, gaux=None, gaux_raw=False):
+    """dx[M,K] = ((dy[M,N] @ w[N,K]) * rowscale) * (gaux if gaux_raw else gelu'(gaux))"""
     M, N = dy.shape
     K = w.shape[1]
     gemm(dy, w, dx, M, K, N, N, K, K, 1, 0, rowscale=rowscale, rows_per_scale=rows_per_scale, gaux=gaux, ldg=K,
-         mode=mode)
+         mode=mode, gaux_raw=gaux_raw)
 
 
 def linear_bwd_weight(dy, x, dw, db, mode, x_op=0, kscale=None, k_per_scale=0):
@@ -86,10 +86,13 @@ def winattn_bwd(qkv, table, dout, dqkv, dtable, B, hw, Cc, shift, mode):
                              _stream()), "wm_winattn_bwd")
 
 
-def dwconv_fwd(h1, w, b, h2, B, hw, Ch, a2=None):
-    if _bf(h1) != _bf(h2) or (a2 is not None and _bf(a2) != _bf(h2)):
-        raise ValueError("dwconv: h1, h2 and a2 must share a storage type")
-    check(lib.wm_dwconv_fwd(ptr(h1), ptr(w), ptr(b), ptr(h2), ptr(a2), _bf(h1), B, hw, Ch, _stream()), "wm_dwconv_fwd")
+def dwconv_fwd(h1, w, b, h2, B, hw, Ch, a2=None, g2=None):
+    """h2 = dwconv3x3(gelu(h1)) + b (optional output), a2 = gelu(h2), g2 = gelu'(h2)"""
+    for t in (h2, a2, g2):
+        if t is not None and _bf(t) != _bf(h1):
+            raise ValueError("dwconv: all tensors must share a storage type")
+    check(lib.wm_dwconv_fwd(ptr(h1), ptr(w), ptr(b), ptr(h2), ptr(a2), ptr(g2), _bf(h1), B, hw, Ch, _stream()),
+          "wm_dwconv_fwd")
 
 
 def dwconv_bwd(h1, dh2, w, dh1, dw, db, B, hw, Ch):

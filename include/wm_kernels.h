@@ -48,6 +48,7 @@ typedef struct WmGemm {
   int32_t ksplit;            /* >=1 number of K splits (needs atomic_out when >1); 0 = auto     */
   int32_t mode;
   int32_t a_bf16, b_bf16, c_bf16, gaux_bf16; /* storage type of A / B / C / gaux: 0 fp32, 1 bf16 (bf16 C: no atomics)   */
+  int32_t gaux_raw;          /* 1: gaux already holds the factor (gelu'(h2) saved by wm_dwconv_fwd): plain multiply  */
 } WmGemm;
 int wm_gemm(const WmGemm* g, void* stream);
 
@@ -71,8 +72,8 @@ int wm_winattn_bwd(const void* qkv, const float* bias_table, const void* dout, v
 /* ---- LeFF depthwise 3x3 on token-major [B,hw,hw,Ch] — model.py:703-709.  Input is the
  * PRE-GELU linear1 output; GELU is applied while staging.  Outputs: h2 (pre-GELU, kept for gelu' in
  * backward) and optionally a2 = GELU(h2), the A operand of linear2.                            */
-int wm_dwconv_fwd(const void* h1, const float* w, const float* b, void* h2, void* a2 /* gelu(h2) or NULL */,
-                  int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream);
+int wm_dwconv_fwd(const void* h1, const float* w, const float* b, void* h2 /* or NULL */, void* a2 /* gelu(h2) or NULL */,
+                  void* g2 /* gelu'(h2) or NULL */, int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream);
 /* dh1 = gelu'(h1) * conv^T(dh2);  dw[Ch,9], db[Ch] accumulated */
 int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, void* dh1, float* dw, float* db,
                   int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream);

@@ -75,6 +75,8 @@ def test_gemm_backward_layouts(wm, mode, M, N, K):
     g = torch.autograd.functional.jvp(F.gelu, aux, torch.ones_like(aux))[1]
     ref = (dy @ w) * rs.repeat_interleave(rows_per)[:M, None] * g
     assert_close(dx, ref, TOL[mode], "linear_bwd_input")
+    ops.linear_bwd_input(dev(dy), dev(w), dx, mode, rowscale=dev(rs), rows_per_scale=rows_per, gaux=dev(aux), gaux_raw=True)
+    assert_close(dx, (dy @ w) * rs.repeat_interleave(rows_per)[:M, None] * aux, TOL[mode], "linear_bwd_input raw aux")
     for ks in (0, 1, 3):
         dw = torch.zeros(N, K, device="cuda")
         db = torch.zeros(N, device="cuda")
@@ -184,10 +186,12 @@ def test_dwconv_fwd_bwd(wm, hw, Ch):
     ref.backward(g)
     h2 = torch.empty(B, hw, hw, Ch, device="cuda")
     hd, wd = dev(h1.detach()), dev(w.detach())
-    a2 = torch.empty_like(h2)
-    ops.dwconv_fwd(hd, wd, dev(b.detach()), h2, B, hw, Ch, a2=a2)
+    a2, g2 = torch.empty_like(h2), torch.empty_like(h2)
+    ops.dwconv_fwd(hd, wd, dev(b.detach()), h2, B, hw, Ch, a2=a2, g2=g2)
     assert_close(h2, ref.detach(), 1e-5, "dwconv fwd")
     assert_close(a2, F.gelu(ref.detach()), 1e-5, "dwconv fwd gelu output")
+    gref = torch.autograd.functional.jvp(F.gelu, ref.detach(), torch.ones_like(ref.detach()))[1]
+    assert_close(g2, gref, 1e-5, "dwconv fwd gelu' output")
     dh1 = torch.empty_like(hd)
     dwg, dbg = torch.zeros(Ch, 9, device="cuda"), torch.zeros(Ch, device="cuda")
     ops.dwconv_bwd(hd, dev(g), wd, dh1, dwg, dbg, B, hw, Ch)
