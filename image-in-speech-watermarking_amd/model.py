@@ -367,7 +367,8 @@ class UformerAudio(nn.Module):
         qkv = H(dev, M, 3 * C)
         ops.linear_fwd(xn1, W(pre + "attn.qkv.w"), P[pre + "attn.qkv.b"], qkv, mode)
         o = H(dev, M, C)
-        ops.winattn_fwd(qkv, P[pre + "attn.relative_position_bias_table"], o, B, hw, C, shift, mode)
+        lse = _E(dev, M, C // 32) if self.compute_mode == "bf16" else None
+        ops.winattn_fwd(qkv, P[pre + "attn.relative_position_bias_table"], o, B, hw, C, shift, mode, lse=lse)
         x1 = _E(dev, M, C)
         ops.linear_fwd(o, W(pre + "attn.proj.weight"), P[pre + "attn.proj.bias"], x1, mode, res=x, rowscale=s1, rows_per_scale=N)
         xn2, mean2, rstd2 = H(dev, M, C), _E(dev, M), _E(dev, M)
@@ -379,10 +380,10 @@ class UformerAudio(nn.Module):
         x2 = _E(dev, M, C)
         ops.linear_fwd(a2, W(pre + "mlp.linear2.0.weight"), P[pre + "mlp.linear2.0.bias"], x2, mode, res=x1,
                        rowscale=s2, rows_per_scale=N)
-        return x2, (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2)
+        return x2, (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2, lse)
 
     def _block_bwd(self, sv, dy):
-        (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2) = sv
+        (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2, lse) = sv
         P, G, dev, mode = self._views, self._gviews, x.device, self._mode()
         M, N = x.shape[0], hw * hw
         # LeFF
@@ -406,7 +407,7 @@ class UformerAudio(nn.Module):
         ops.linear_bwd_weight(dx1, o, G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], mode, kscale=s1, k_per_scale=N)
         dqkv = H(dev, M, 3 * C)
         ops.winattn_bwd(qkv, P[pre + "attn.relative_position_bias_table"], do, dqkv,
-                        G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, mode)
+                        G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, mode, out=o, lse=lse)
         dxn1 = H(dev, M, C)
         ops.linear_bwd_input(dqkv, W(pre + "attn.qkv.w"), dxn1, mode)
         ops.linear_bwd_weight(dqkv, xn1, G[pre + "attn.qkv.w"], G[pre + "attn.qkv.b"], mode)

@@ -73,17 +73,18 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dmod, hw, s
                                ptr(dgamma), ptr(dbeta), ptr(dmod), rows, Cc, hw, shift, _stream()), "wm_layernorm_bwd")
 
 
-def winattn_fwd(qkv, table, out, B, hw, Cc, shift, mode):
+def winattn_fwd(qkv, table, out, B, hw, Cc, shift, mode, lse=None):
     if _bf(qkv) != _bf(out):
         raise ValueError("winattn: qkv and out must share a storage type")
-    check(lib.wm_winattn_fwd(ptr(qkv), ptr(table), ptr(out), _bf(qkv), B, hw, Cc, shift, mode, _stream()), "wm_winattn_fwd")
+    check(lib.wm_winattn_fwd(ptr(qkv), ptr(table), ptr(out), ptr(lse), _bf(qkv), B, hw, Cc, shift, mode, _stream()),
+          "wm_winattn_fwd")
 
 
-def winattn_bwd(qkv, table, dout, dqkv, dtable, B, hw, Cc, shift, mode):
-    if not (_bf(qkv) == _bf(dout) == _bf(dqkv)):
-        raise ValueError("winattn_bwd: qkv, dout and dqkv must share a storage type")
-    check(lib.wm_winattn_bwd(ptr(qkv), ptr(table), ptr(dout), ptr(dqkv), ptr(dtable), _bf(qkv), B, hw, Cc, shift, mode,
-                             _stream()), "wm_winattn_bwd")
+def winattn_bwd(qkv, table, dout, dqkv, dtable, B, hw, Cc, shift, mode, out=None, lse=None):
+    if not (_bf(qkv) == _bf(dout) == _bf(dqkv)) or (out is not None and _bf(out) != _bf(qkv)):
+        raise ValueError("winattn_bwd: qkv, out, dout and dqkv must share a storage type")
+    check(lib.wm_winattn_bwd(ptr(qkv), ptr(table), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), ptr(dtable), _bf(qkv), B, hw,
+                             Cc, shift, mode, _stream()), "wm_winattn_bwd")
 
 
 def dwconv_fwd(h1, w, b, h2, B, hw, Ch, a2=None, g2=None):

@@ -34,8 +34,8 @@ def _attn_cost(B, hw, C, products):
 
 COST = {
     "gemm": lambda *a, **k: _gemm_cost(a + (k,)),
-    "winattn_fwd": lambda qkv, t, o, B, hw, C, sh, mode: (_attn_cost(B, hw, C, 2), qkv.element_size() * B * hw * hw * 4.0 * C),
-    "winattn_bwd": lambda qkv, t, do, dq, dt, B, hw, C, sh, mode: (_attn_cost(B, hw, C, 6), qkv.element_size() * B * hw * hw * 7.0 * C),
+    "winattn_fwd": lambda qkv, t, o, B, hw, C, sh, mode, lse=None: (_attn_cost(B, hw, C, 2), qkv.element_size() * B * hw * hw * 4.0 * C),
+    "winattn_bwd": lambda qkv, t, do, dq, dt, B, hw, C, sh, mode, out=None, lse=None: (_attn_cost(B, hw, C, 6), qkv.element_size() * B * hw * hw * 7.0 * C),
     "dwconv_fwd": lambda h1, w, b, h2, B, hw, Ch, a2=None, g2=None: (18.0 * B * hw * hw * Ch, (1.0 + sum(t is not None for t in (h2, a2, g2))) * h1.element_size() * B * hw * hw * Ch),
     "dwconv_bwd": lambda h1, d, w, dh, dw, db, B, hw, Ch: (54.0 * B * hw * hw * Ch, 3.0 * h1.element_size() * B * hw * hw * Ch),
     "layernorm_fwd": lambda x, g, b, m, y, *a: (8.0 * x.numel(), (4.0 + y.element_size()) * x.numel()),
@@ -92,9 +92,11 @@ class KernelTimer:
         if self.detail and name in ("dwconv_bwd", "dwconv_fwd", "layernorm_bwd", "winattn_bwd", "winattn_fwd"):
             sz = args[0].numel()
             tag = f"{name}_n{sz}"
-            return (tag + ("_bf16" if name.startswith("winattn") and args[-1] else "")), (args[-1] if name.startswith("winattn") else None)
+            md = args[9 if name == "winattn_bwd" else 7] if name.startswith("winattn") else None
+            return (tag + ("_bf16" if md else "")), md
         if name.startswith("winattn"):
-            return f"{name}_{'bf16' if args[-1] else 'f32'}", args[-1]
+            md = args[9 if name == "winattn_bwd" else 7]
+            return f"{name}_{'bf16' if md else 'f32'}", md
         return name, None
 
     def __enter__(self):

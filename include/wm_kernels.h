@@ -63,10 +63,13 @@ int wm_layernorm_bwd(const void* dy, int32_t dy_bf16, const float* x, const floa
 
 /* ---- 8x8 window attention — model.py:523-551 with roll/partition/reverse (:987-1013) and the
  * shift mask (:954-972) folded into the indexing.  qkv: [B*hw*hw, 3C] (q|k|v), heads of 32.    */
-int wm_winattn_fwd(const void* qkv, const float* bias_table, void* out, int32_t io_bf16, int32_t B, int32_t hw,
-                   int32_t C, int32_t shift, int32_t mode, void* stream);
-int wm_winattn_bwd(const void* qkv, const float* bias_table, const void* dout, void* dqkv,
-                   float* dbias_table, int32_t io_bf16, int32_t B, int32_t hw, int32_t C, int32_t shift,
+/* lse (optional, fp32 [tokens, heads]): log-sum-exp of every softmax row, saved for the fast backward            */
+int wm_winattn_fwd(const void* qkv, const float* bias_table, void* out, float* lse, int32_t io_bf16, int32_t B,
+                   int32_t hw, int32_t C, int32_t shift, int32_t mode, void* stream);
+/* out / lse: the forward's results; when both are given in mode 1 the register-resident backward is used,
+ * otherwise (NULL, or mode 0) scores are re-normalised through LDS                                              */
+int wm_winattn_bwd(const void* qkv, const float* bias_table, const void* out, const float* lse, const void* dout,
+                   void* dqkv, float* dbias_table, int32_t io_bf16, int32_t B, int32_t hw, int32_t C, int32_t shift,
                    int32_t mode, void* stream);
 
 /* ---- LeFF depthwise 3x3 on token-major [B,hw,hw,Ch] — model.py:703-709.  Input is the

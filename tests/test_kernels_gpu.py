@@ -164,13 +164,19 @@ def test_winattn_fwd_bwd(wm, mode, hw, C, shift):
     ref.backward(do)
     out = torch.empty(B * hw * hw, C, device="cuda")
     qd, td = dev(qkv.detach()), dev(table.detach())
-    ops.winattn_fwd(qd, td, out, B, hw, C, shift, mode)
+    lse = torch.empty(B * hw * hw, heads, device="cuda")
+    ops.winattn_fwd(qd, td, out, B, hw, C, shift, mode, lse=lse)
     assert_close(out, ref.detach(), TOL[mode], "attn fwd")
     dqkv = torch.empty_like(qd)
     dtab = torch.zeros_like(td)
     ops.winattn_bwd(qd, td, dev(do), dqkv, dtab, B, hw, C, shift, mode)
     assert_close(dqkv, qkv.grad, TOL[mode] * (2 if mode else 1), "attn dqkv")
     assert_close(dtab, table.grad, TOL[mode] * (2 if mode else 1), "attn dtable")
+    if mode == 1:       # register-resident backward: needs the forward's output and row log-sum-exp
+        dq2, dt2 = torch.empty_like(qd), torch.zeros_like(td)
+        ops.winattn_bwd(qd, td, dev(do), dq2, dt2, B, hw, C, shift, mode, out=out, lse=lse)
+        assert_close(dq2, qkv.grad, TOL[mode] * 2, "attn dqkv (fast)")
+        assert_close(dt2, table.grad, TOL[mode] * 2, "attn dtable (fast)")
 
 
 # ------------------------------------------------------------------------------------ dwconv
@@ -540,10 +546,11 @@ def test_elementwise_kernels_bf16_storage(wm):
     ref.backward(do)
     out = torch.empty(rows, C, device="cuda", dtype=bf)
     qd = dev(qkv.detach()).to(bf)
-    ops.winattn_fwd(qd, dev(table.detach()), out, B, hw, C, 4, 1)
+    lse = torch.empty(B * hw * hw, C // 32, device="cuda")
+    ops.winattn_fwd(qd, dev(table.detach()), out, B, hw, C, 4, 1, lse=lse)
     assert_close(out.float(), ref.detach(), 3e-2, "attn fwd bf16 io")
     dqkv, dtab = torch.empty_like(qd), torch.zeros(225, heads, device="cuda")
-    ops.winattn_bwd(qd, dev(table.detach()), dev(do).to(bf), dqkv, dtab, B, hw, C, 4, 1)
+    ops.winattn_bwd(qd, dev(table.detach()), dev(do).to(bf), dqkv, dtab, B, hw, C, 4, 1, out=out, lse=lse)
     assert_close(dqkv.float(), qkv.grad, 5e-2, "attn bwd bf16 io")
     # depthwise conv
     Ch = 128
