@@ -44,7 +44,8 @@ _SIGS = {
     "wm_layernorm_fwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f],
     "wm_layernorm_bwd": [c_f, c_i32] + [c_f] * 9 + [c_i64, c_i32, c_i32, c_i32, c_f],
     "wm_winattn_fwd": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
-    "wm_winattn_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_winattn_bwd_scratch_floats": [],
+    "wm_winattn_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_dwconv_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_dwconv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_im2col_4x4s2": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
@@ -89,7 +90,7 @@ def _load():
     for name, args in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError here = ABI drift between header and library
         fn.argtypes = args
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name.endswith("_floats") else C.c_int
     return lib
 
 

@@ -286,6 +286,13 @@ class UformerAudio(nn.Module):
     def _H(self, dev, *shape):
         return torch.empty(shape, device=dev, dtype=torch.bfloat16 if self.compute_mode == "bf16" else torch.float32)
 
+    def _attn_scratch(self, dev):
+        """Per-workgroup partial sums of the bias-table gradient (wm_winattn_bwd): one buffer, reused by every block."""
+        sc = getattr(self, "_attn_scr", None)
+        if sc is None or sc.device != dev:
+            sc = self._attn_scr = torch.empty(int(ops.lib.wm_winattn_bwd_scratch_floats()), device=dev)
+        return sc
+
     def _refresh_weight_copy(self):
         if self.compute_mode != "bf16":
             return
@@ -407,7 +414,8 @@ class UformerAudio(nn.Module):
         ops.linear_bwd_weight(dx1, o, G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], mode, kscale=s1, k_per_scale=N)
         dqkv = H(dev, M, 3 * C)
         ops.winattn_bwd(qkv, P[pre + "attn.relative_position_bias_table"], do, dqkv,
-                        G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, mode, out=o, lse=lse)
+                        G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, mode, out=o, lse=lse,
+                        scratch=self._attn_scratch(dev))
         dxn1 = H(dev, M, C)
         ops.linear_bwd_input(dqkv, W(pre + "attn.qkv.w"), dxn1, mode)
         ops.linear_bwd_weight(dqkv, xn1, G[pre + "attn.qkv.w"], G[pre + "attn.qkv.b"], mode)

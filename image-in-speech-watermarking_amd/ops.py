@@ -80,11 +80,13 @@ def winattn_fwd(qkv, table, out, B, hw, Cc, shift, mode, lse=None):
           "wm_winattn_fwd")
 
 
-def winattn_bwd(qkv, table, dout, dqkv, dtable, B, hw, Cc, shift, mode, out=None, lse=None):
+def winattn_bwd(qkv, table, dout, dqkv, dtable, B, hw, Cc, shift, mode, out=None, lse=None, scratch=None):
+    if scratch is not None and scratch.numel() < lib.wm_winattn_bwd_scratch_floats():
+        raise ValueError("winattn_bwd: scratch buffer too small")
     if not (_bf(qkv) == _bf(dout) == _bf(dqkv)) or (out is not None and _bf(out) != _bf(qkv)):
         raise ValueError("winattn_bwd: qkv, out, dout and dqkv must share a storage type")
-    check(lib.wm_winattn_bwd(ptr(qkv), ptr(table), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), ptr(dtable), _bf(qkv), B, hw,
-                             Cc, shift, mode, _stream()), "wm_winattn_bwd")
+    check(lib.wm_winattn_bwd(ptr(qkv), ptr(table), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), ptr(dtable), ptr(scratch),
+                             _bf(qkv), B, hw, Cc, shift, mode, _stream()), "wm_winattn_bwd")
 
 
 def dwconv_fwd(h1, w, b, h2, B, hw, Ch, a2=None, g2=None):

@@ -66,11 +66,14 @@ int wm_layernorm_bwd(const void* dy, int32_t dy_bf16, const float* x, const floa
 /* lse (optional, fp32 [tokens, heads]): log-sum-exp of every softmax row, saved for the fast backward            */
 int wm_winattn_fwd(const void* qkv, const float* bias_table, void* out, float* lse, int32_t io_bf16, int32_t B,
                    int32_t hw, int32_t C, int32_t shift, int32_t mode, void* stream);
-/* out / lse: the forward's results; when both are given in mode 1 the register-resident backward is used,
- * otherwise (NULL, or mode 0) scores are re-normalised through LDS                                              */
+/* out / lse: the forward's results; when both are given in mode 1 with bf16 storage the register-resident backward
+ * is used, otherwise (NULL, fp32 storage or mode 0) scores are re-normalised through LDS.
+ * scratch (optional, device, >= wm_winattn_bwd_scratch_floats() floats, contents irrelevant): per-workgroup partial
+ * sums of the relative-position-bias gradient, reduced by a second kernel; NULL = global atomics (slower).        */
+int64_t wm_winattn_bwd_scratch_floats(void);
 int wm_winattn_bwd(const void* qkv, const float* bias_table, const void* out, const float* lse, const void* dout,
-                   void* dqkv, float* dbias_table, int32_t io_bf16, int32_t B, int32_t hw, int32_t C, int32_t shift,
-                   int32_t mode, void* stream);
+                   void* dqkv, float* dbias_table, float* scratch, int32_t io_bf16, int32_t B, int32_t hw, int32_t C,
+                   int32_t shift, int32_t mode, void* stream);
 
 /* ---- LeFF depthwise 3x3 on token-major [B,hw,hw,Ch] — model.py:703-709.  Input is the
  * PRE-GELU linear1 output; GELU is applied while staging.  Outputs: h2 (pre-GELU, kept for gelu' in
