@@ -42,12 +42,14 @@ _SIGS = {
     "wm_abi_version": [],
     "wm_gemm": [C.POINTER(WmGemm), c_f],
     "wm_layernorm_fwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f],
-    "wm_layernorm_bwd": [c_f, c_i32] + [c_f] * 9 + [c_i64, c_i32, c_i32, c_i32, c_f],
+    "wm_layernorm_bwd_scratch_floats": [c_i32],
+    "wm_layernorm_bwd": [c_f, c_i32] + [c_f] * 10 + [c_i64, c_i32, c_i32, c_i32, c_f],
     "wm_winattn_fwd": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_winattn_bwd_scratch_floats": [],
     "wm_winattn_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_dwconv_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
-    "wm_dwconv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_dwconv_bwd_scratch_floats": [c_i32, c_i32, c_i32],
+    "wm_dwconv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_im2col_4x4s2": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_col2im_4x4s2": [c_f, c_i32, c_f, c_i32, c_i32, c_i32, c_f],
     "wm_pixel_shuffle2": [c_f, c_i32, c_f, c_f, c_i32, c_i32, c_i32, c_i64, c_i32, c_f],

@@ -25,7 +25,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 //   erf(z) = sign(z) * (1 - (a1 t + ... + a5 t^5) exp(-z^2)),  t = 1 / (1 + p |z|)
 // With z = x/sqrt(2) the exponential exp(-x^2/2) is shared by gelu'(x) = Phi(x) + x phi(x).
 __device__ __forceinline__ float phi_tail_f(float x, float e) {          // 0.5 * erfc(|x|/sqrt2), e = exp(-x^2/2)
-  const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));   // v_rcp_f32 (1 ulp), not the IEEE division sequence
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);

@@ -2,7 +2,12 @@
 // model.py:703-709: rearrange -> Conv2d(groups=Ch, k=3, p=1) -> GELU -> rearrange).  The token-major
 // layout makes the channel dim contiguous, so no b(hw)c <-> bchw transposes are materialised.
 // Input is linear1's PRE-activation; GELU is applied once per staged element (tile + halo in LDS).
-// Output is the pre-activation of the second GELU (applied by the consumer GEMM while staging).
+//
+// Work split: a 256-thread workgroup owns an 8x8-pixel tile x 64 channels; a thread owns TWO channels of one tile row
+// (8 pixels), so the 3x3 window slides along x in registers (30 LDS reads per 8 outputs instead of 72) and every
+// multiply-add is a packed 2 x fp32 instruction.  Global traffic is 16-byte chunks, all issued before the first use
+// (the compiler does not hoist loads across LDS stores by itself), and the backward kernel walks a strip of tiles
+// with the next tile's loads in flight while the current one is computed.
 #include "common.h"
 #include "../../include/wm_kernels.h"
 
@@ -11,20 +16,110 @@ namespace {
 constexpr int TP = 8;              // tile is TP x TP pixels
 constexpr int HP = TP + 2;         // with halo
 constexpr int TC = 64;             // channels per workgroup
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+// a = x Phi(x), g = Phi(x) + x phi(x) for two values (same Abramowitz-Stegun form as gelu_f; packed arithmetic)
+__device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& a, f32x2& g) {
+  f32x2 e, t;
+  e.x = __expf(-0.5f * x.x * x.x);
+  e.y = __expf(-0.5f * x.y * x.y);
+  const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+  const f32x2 den = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
+  t.x = __builtin_amdgcn_rcpf(den.x);                           // v_rcp_f32 (1 ulp), not the IEEE division sequence
+  t.y = __builtin_amdgcn_rcpf(den.y);
+  f32x2 p = t * 1.061405429f - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const f32x2 q = p * t * e * 0.5f;                           // Phi(-|x|)
+  const f32x2 cdf = {x.x >= 0.f ? 1.0f - q.x : q.x, x.y >= 0.f ? 1.0f - q.y : q.y};
+  a = x * cdf;
+  g = cdf + x * e * 0.39894228040143268f;
+}
+
+template <typename ST> struct Chunk;                          // one 16-byte global chunk
+template <> struct Chunk<__bf16> {
+  static constexpr int NE = 8;
+  static __device__ __forceinline__ void unpack(u32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf_lo(v[i]); f[2 * i + 1] = bf_hi(v[i]); }
+  }
+};
+template <> struct Chunk<float> {
+  static constexpr int NE = 4;
+  static __device__ __forceinline__ void unpack(u32x4 v, float (&f)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
+  }
+};
+template <typename ST> struct Halo {
+  static constexpr int NE = Chunk<ST>::NE, CPP = TC / NE, NCH = HP * HP * CPP, NL = (NCH + 255) / 256;
+};
+
+// two adjacent channels of one pixel
+template <typename ST> struct Pair;
+template <> struct Pair<__bf16> {
+  typedef uint32_t raw;
+  static __device__ __forceinline__ f32x2 up(raw u) { f32x2 v = {bf_lo(u), bf_hi(u)}; return v; }
+  static __device__ __forceinline__ raw down(f32x2 v) { return pack_bf2(v.x, v.y); }
+};
+template <> struct Pair<float> {
+  typedef float2 raw;
+  static __device__ __forceinline__ f32x2 up(raw u) { f32x2 v = {u.x, u.y}; return v; }
+  static __device__ __forceinline__ raw down(f32x2 v) { return make_float2(v.x, v.y); }
+};
+
+// (tile + halo) x 64 channels of `src` into registers; out-of-image pixels read a clamped address and become zero
 template <typename ST>
-__device__ __forceinline__ void load_halo_tile(float* tile, const ST* __restrict__ src, int b, int ty, int tx,
-                                               int hw, int Ch, int cbase, bool gelu, int tid) {
-  for (int idx = tid; idx < HP * HP * (TC / 4); idx += 256) {
-    const int pix = idx / (TC / 4), c4 = idx % (TC / 4);
-    const int ly = pix / HP, lx = pix % HP;
+__device__ __forceinline__ void halo_load(u32x4 (&c)[Halo<ST>::NL], const ST* __restrict__ src, int b, int ty, int tx,
+                                          int hw, int Ch, int cbase, int tid) {
+  typedef Halo<ST> H;
+#pragma unroll
+  for (int k = 0; k < H::NL; ++k) {
+    int idx = tid + 256 * k;
+    idx = idx < H::NCH ? idx : H::NCH - 1;
+    const int pix = idx / H::CPP, part = idx - pix * H::CPP;
+    const int ly = pix / HP, lx = pix - ly * HP;
     const int gy = ty * TP + ly - 1, gx = tx * TP + lx - 1;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gy >= 0 && gy < hw && gx >= 0 && gx < hw) {
-      v = IO<ST>::ld4(src + (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4);
-      if (gelu) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+    const bool inb = (unsigned)gy < (unsigned)hw && (unsigned)gx < (unsigned)hw;
+    const int cy = min(max(gy, 0), hw - 1), cx = min(max(gx, 0), hw - 1);
+    u32x4 v = *reinterpret_cast<const u32x4*>(src + (((int64_t)b * hw + cy) * hw + cx) * Ch + cbase + part * H::NE);
+    if (!inb) v = (u32x4){0u, 0u, 0u, 0u};
+    c[k] = v;
+  }
+}
+template <typename ST, bool GELU>
+__device__ __forceinline__ void halo_to_lds(float* tile, const u32x4 (&c)[Halo<ST>::NL], int tid) {
+  typedef Halo<ST> H;
+#pragma unroll
+  for (int k = 0; k < H::NL; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < H::NCH) {
+      float f[H::NE];
+      Chunk<ST>::unpack(c[k], f);
+      if (GELU) {
+#pragma unroll
+        for (int i = 0; i < H::NE; i += 2) {
+          f32x2 a, g;
+          gelu_pair((f32x2){f[i], f[i + 1]}, a, g);
+          f[i] = a.x;
+          f[i + 1] = a.y;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < H::NE; i += 4)
+        *reinterpret_cast<float4*>(tile + idx * H::NE + i) = make_float4(f[i], f[i + 1], f[i + 2], f[i + 3]);
     }
-    *reinterpret_cast<float4*>(tile + pix * TC + 4 * c4) = v;
+  }
+}
+
+// wl[k][c] = w[cbase + c][k] (k < 9), wl[9][c] = bias[cbase + c] (or 0)
+__device__ __forceinline__ void stage_weights(float* wl, const float* __restrict__ w, const float* __restrict__ bias,
+                                              int cbase, int tid) {
+  for (int i = tid; i < 10 * TC; i += 256) {
+    const int k = i / TC, c = i - k * TC;
+    wl[i] = k < 9 ? w[(cbase + c) * 9 + k] : (bias ? bias[cbase + c] : 0.f);
   }
 }
 
@@ -34,49 +129,47 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ST* __restrict__ 
                                                          ST* __restrict__ a2, ST* __restrict__ g2, int B, int hw,
                                                          int Ch) {
   __shared__ __attribute__((aligned(16))) float tile[HP * HP * TC];
+  __shared__ __attribute__((aligned(16))) float wl[10 * TC];
   const int tid = threadIdx.x, nt = hw / TP;
   const int t = blockIdx.x, b = t / (nt * nt), tr = t - b * nt * nt, ty = tr / nt, tx = tr - ty * nt;
   const int cbase = blockIdx.y * TC;
-  load_halo_tile(tile, h1, b, ty, tx, hw, Ch, cbase, true, tid);
-  const int c4 = tid & 15, pg = tid >> 4;
-  float wr[4][9], br[4];
-#pragma unroll
-  for (int cc = 0; cc < 4; ++cc) {
-    br[cc] = bias[cbase + 4 * c4 + cc];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) wr[cc][k] = w[(cbase + 4 * c4 + cc) * 9 + k];
-  }
+  u32x4 hreg[Halo<ST>::NL];
+  halo_load<ST>(hreg, h1, b, ty, tx, hw, Ch, cbase, tid);
+  stage_weights(wl, w, bias, cbase, tid);
+  halo_to_lds<ST, true>(tile, hreg, tid);
   __syncthreads();
+  const int c2 = tid & 31, py = tid >> 5;
+  f32x2 wr[9], br;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int pix = pg * 4 + q, py = pix >> 3, px = pix & 7;
-    float o[4] = {br[0], br[1], br[2], br[3]};
+  for (int k = 0; k < 9; ++k) wr[k] = *reinterpret_cast<const f32x2*>(wl + k * TC + 2 * c2);
+  br = *reinterpret_cast<const f32x2*>(wl + 9 * TC + 2 * c2);
+  f32x2 col[3][3];                                            // col[x % 3][dy]
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) col[x][dy] = *reinterpret_cast<const f32x2*>(tile + ((py + dy) * HP + x) * TC + 2 * c2);
+  const int64_t row0 = (((int64_t)b * hw + ty * TP + py) * hw + tx * TP) * Ch + cbase + 2 * c2;
+#pragma unroll
+  for (int px = 0; px < TP; ++px) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+      col[(px + 2) % 3][dy] = *reinterpret_cast<const f32x2*>(tile + ((py + dy) * HP + px + 2) * TC + 2 * c2);
+    f32x2 o = br;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const float4 a = *reinterpret_cast<const float4*>(tile + ((py + dy) * HP + px + dx) * TC + 4 * c4);
-        o[0] += wr[0][dy * 3 + dx] * a.x; o[1] += wr[1][dy * 3 + dx] * a.y;
-        o[2] += wr[2][dy * 3 + dx] * a.z; o[3] += wr[3][dy * 3 + dx] * a.w;
-      }
-    const int gy = ty * TP + py, gx = tx * TP + px;
-    const int64_t off = (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4;
-    if (h2) IO<ST>::st4(h2 + off, make_float4(o[0], o[1], o[2], o[3]));
+      for (int dx = 0; dx < 3; ++dx) o += wr[dy * 3 + dx] * col[(px + dx) % 3][dy];
+    const int64_t off = row0 + (int64_t)px * Ch;
+    typedef typename Pair<ST>::raw raw;
+    if (h2) *reinterpret_cast<raw*>(h2 + off) = Pair<ST>::down(o);
     // second GELU and its derivative are materialised once here, from one shared exp(): evaluating them inside the
     // consumer GEMMs (A-operand staging of linear2 / dW2, epilogue of d_h2) repeated them per column tile and made
     // those launches VALU-bound
     if (a2 || g2) {
-      float av[4], gv[4];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const float e = __expf(-0.5f * o[cc] * o[cc]);
-        const float t = phi_tail_f(o[cc], e);
-        const float cdf = o[cc] >= 0.f ? 1.0f - t : t;
-        av[cc] = o[cc] * cdf;
-        gv[cc] = cdf + o[cc] * 0.39894228040143268f * e;
-      }
-      if (a2) IO<ST>::st4(a2 + off, make_float4(av[0], av[1], av[2], av[3]));
-      if (g2) IO<ST>::st4(g2 + off, make_float4(gv[0], gv[1], gv[2], gv[3]));
+      f32x2 av, gv;
+      gelu_pair(o, av, gv);
+      if (a2) *reinterpret_cast<raw*>(a2 + off) = Pair<ST>::down(av);
+      if (g2) *reinterpret_cast<raw*>(g2 + off) = Pair<ST>::down(gv);
     }
   }
 }
@@ -84,76 +177,121 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ST* __restrict__ 
 // dh1 = gelu'(h1) * sum_k w[k] * dh2[p - off_k];  dw[c][k] += sum_q gelu(h1)[q] * dh2[q - off_k];  db += sum dh2.
 // Only dh2 needs a halo: the weight gradient is written as a sum over the CENTRE pixels q of a1[q] * dh2[q - off]
 // (zero padding of the dh2 halo outside the image makes it equal to the usual sum over p of dh2[p] * a1[p + off]),
-// so every tap needs ONE LDS read that feeds both the transposed convolution and the weight gradient, and
-// gelu / gelu' of h1 are evaluated once per element from one shared exp().
+// so every tap feeds both the transposed convolution and the weight gradient, and gelu / gelu' of h1 are evaluated
+// once per element from one shared exp().
+// One workgroup walks the strip of tiles (b, ty, *) for 64 channels.  The weight / bias gradients stay in registers
+// over the strip; at the end they are reduced over the 8 tile rows and either stored to `part` (one slot per
+// workgroup, summed by dwconv_grad_reduce_kernel) or added with global atomics when there is no scratch buffer.
 template <typename ST>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ST* __restrict__ h1, const ST* __restrict__ dh2,
                                                          const float* __restrict__ w, ST* __restrict__ dh1,
-                                                         float* __restrict__ dw, float* __restrict__ db, int B,
-                                                         int hw, int Ch) {
+                                                         float* __restrict__ dw, float* __restrict__ db,
+                                                         float* __restrict__ part, int B, int hw, int Ch) {
   __shared__ __attribute__((aligned(16))) float tg[HP * HP * TC];      // dh2 with halo
-  __shared__ float wacc[TC * 10];
+  __shared__ __attribute__((aligned(16))) float wl[10 * TC];
+  typedef typename Pair<ST>::raw raw;
   const int tid = threadIdx.x, nt = hw / TP;
   const int b = blockIdx.x / nt, ty = blockIdx.x % nt;
   const int cbase = blockIdx.y * TC;
-  const int c4 = tid & 15, pg = tid >> 4;
-  float wr[4][9], aw[4][9], ab[4];
+  const int c2 = tid & 31, py = tid >> 5;
+  u32x4 hreg[Halo<ST>::NL];
+  raw hn[TP], hc[TP];
+  halo_load<ST>(hreg, dh2, b, ty, 0, hw, Ch, cbase, tid);
+  const int64_t strip0 = (((int64_t)b * hw + ty * TP + py) * hw) * Ch + cbase + 2 * c2;
 #pragma unroll
-  for (int cc = 0; cc < 4; ++cc) {
-    ab[cc] = 0.f;
+  for (int px = 0; px < TP; ++px) hn[px] = *reinterpret_cast<const raw*>(h1 + strip0 + (int64_t)px * Ch);
+  stage_weights(wl, w, nullptr, cbase, tid);
+  __syncthreads();
+  f32x2 wr[9], aw[9], ab = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { wr[cc][k] = w[(cbase + 4 * c4 + cc) * 9 + k]; aw[cc][k] = 0.f; }
+  for (int k = 0; k < 9; ++k) {
+    wr[k] = *reinterpret_cast<const f32x2*>(wl + k * TC + 2 * c2);
+    aw[k] = (f32x2){0.f, 0.f};
   }
-  for (int i = tid; i < TC * 10; i += 256) wacc[i] = 0.f;
   for (int tx = 0; tx < nt; ++tx) {
     __syncthreads();
-    load_halo_tile(tg, dh2, b, ty, tx, hw, Ch, cbase, false, tid);
-    __syncthreads();
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-      const int pix = pg * 4 + q, py = pix >> 3, px = pix & 7;
-      const int gy = ty * TP + py, gx = tx * TP + px;
-      const int64_t off = (((int64_t)b * hw + gy) * hw + gx) * Ch + cbase + 4 * c4;
-      const float4 hv = IO<ST>::ld4(h1 + off);
-      float a1[4], gp[4];
-      {
-        const float xs[4] = {hv.x, hv.y, hv.z, hv.w};
+    halo_to_lds<ST, false>(tg, hreg, tid);
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const float e = __expf(-0.5f * xs[cc] * xs[cc]);
-          const float t = phi_tail_f(xs[cc], e);
-          const float cdf = xs[cc] >= 0.f ? 1.0f - t : t;
-          a1[cc] = xs[cc] * cdf;
-          gp[cc] = cdf + xs[cc] * 0.39894228040143268f * e;
-        }
-      }
-      float o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int px = 0; px < TP; ++px) hc[px] = hn[px];
+    __syncthreads();
+    {                                                         // next tile's loads fly during this tile's arithmetic
+      const int txn = tx + 1 < nt ? tx + 1 : tx;
+      halo_load<ST>(hreg, dh2, b, ty, txn, hw, Ch, cbase, tid);
+#pragma unroll
+      for (int px = 0; px < TP; ++px) hn[px] = *reinterpret_cast<const raw*>(h1 + strip0 + (int64_t)(txn * TP + px) * Ch);
+    }
+    f32x2 col[3][3];                                          // col[x % 3][row]: dh2 at halo row py + row, halo column x
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) col[x][rr] = *reinterpret_cast<const f32x2*>(tg + ((py + rr) * HP + x) * TC + 2 * c2);
+#pragma unroll
+    for (int px = 0; px < TP; ++px) {
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+        col[(px + 2) % 3][rr] = *reinterpret_cast<const f32x2*>(tg + ((py + rr) * HP + px + 2) * TC + 2 * c2);
+      f32x2 a1, gp;
+      gelu_pair(Pair<ST>::up(hc[px]), a1, gp);
+      f32x2 o = {0.f, 0.f};
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-          const int k = dy * 3 + dx;
-          const float4 g = *reinterpret_cast<const float4*>(tg + ((py + 2 - dy) * HP + px + 2 - dx) * TC + 4 * c4);
-          o[0] += wr[0][k] * g.x; o[1] += wr[1][k] * g.y; o[2] += wr[2][k] * g.z; o[3] += wr[3][k] * g.w;
-          aw[0][k] += a1[0] * g.x; aw[1][k] += a1[1] * g.y; aw[2][k] += a1[2] * g.z; aw[3][k] += a1[3] * g.w;
+          const f32x2 g = col[(px + 2 - dx) % 3][2 - dy];    // dh2 at (py + 1 - (dy - 1), px + 1 - (dx - 1))
+          o += wr[dy * 3 + dx] * g;
+          aw[dy * 3 + dx] += a1 * g;
         }
-      const float4 gc = *reinterpret_cast<const float4*>(tg + ((py + 1) * HP + px + 1) * TC + 4 * c4);
-      ab[0] += gc.x; ab[1] += gc.y; ab[2] += gc.z; ab[3] += gc.w;
-      IO<ST>::st4(dh1 + off, make_float4(o[0] * gp[0], o[1] * gp[1], o[2] * gp[2], o[3] * gp[3]));
+      ab += col[(px + 1) % 3][1];
+      *reinterpret_cast<raw*>(dh1 + strip0 + (int64_t)(tx * TP + px) * Ch) = Pair<ST>::down(o * gp);
     }
   }
+  // reduce the 20 per-thread sums over the 8 tile rows: the two rows of a wave by a lane exchange, the 4 waves via LDS
 #pragma unroll
-  for (int cc = 0; cc < 4; ++cc) {
+  for (int k = 0; k < 9; ++k) {
+    aw[k].x += __shfl_xor(aw[k].x, 32);
+    aw[k].y += __shfl_xor(aw[k].y, 32);
+  }
+  ab.x += __shfl_xor(ab.x, 32);
+  ab.y += __shfl_xor(ab.y, 32);
+  __syncthreads();
+  float* red = tg;                                            // [4 waves][64 channels][10]
+  if ((tid & 63) < 32) {
+    float* dst = red + ((tid >> 6) * TC + 2 * c2) * 10;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) atomicAdd(&wacc[(4 * c4 + cc) * 10 + k], aw[cc][k]);
-    atomicAdd(&wacc[(4 * c4 + cc) * 10 + 9], ab[cc]);
+    for (int k = 0; k < 9; ++k) { dst[k] = aw[k].x; dst[10 + k] = aw[k].y; }
+    dst[9] = ab.x;
+    dst[19] = ab.y;
   }
   __syncthreads();
   for (int i = tid; i < TC * 10; i += 256) {
-    const int c = i / 10, k = i % 10;
-    if (k < 9) atomicAdd(dw + (cbase + c) * 9 + k, wacc[i]);
-    else atomicAdd(db + cbase + c, wacc[i]);
+    const float s = red[i] + red[TC * 10 + i] + red[2 * TC * 10 + i] + red[3 * TC * 10 + i];
+    const int c = i / 10, k = i - c * 10;
+    if (part) part[((int64_t)blockIdx.x * Ch + cbase) * 10 + i] = s;
+    else if (k < 9) atomicAdd(dw + (cbase + c) * 9 + k, s);
+    else atomicAdd(db + cbase + c, s);
   }
+}
+
+// dw[c][k] / db[c] += sum over the P strips of part[p][c][k]; block (x: 256 outputs, y: segment of `per` strips)
+__global__ __launch_bounds__(256) void dwconv_grad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                 float* __restrict__ db, int P, int Ch, int per) {
+  const int i = blockIdx.x * 256 + threadIdx.x, n = Ch * 10;
+  if (i >= n) return;
+  const int p0 = blockIdx.y * per, p1 = min(P, p0 + per);
+  const float* p = part + (int64_t)p0 * n + i;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int q = p0;
+  for (; q + 4 <= p1; q += 4, p += 4 * (int64_t)n) {
+    s0 += p[0];
+    s1 += p[n];
+    s2 += p[2 * (int64_t)n];
+    s3 += p[3 * (int64_t)n];
+  }
+  for (; q < p1; ++q, p += n) s0 += p[0];
+  const float s = (s0 + s1) + (s2 + s3);
+  const int c = i / 10, k = i - c * 10;
+  if (k < 9) atomicAdd(dw + c * 9 + k, s);
+  else atomicAdd(db + c, s);
 }
 
 bool ok(int B, int hw, int Ch) { return B > 0 && hw >= 8 && (hw & 7) == 0 && Ch >= 64 && (Ch & 63) == 0; }
@@ -175,17 +313,29 @@ extern "C" int wm_dwconv_fwd(const void* h1, const float* w, const float* b, voi
   return WM_OK;
 }
 
+extern "C" int64_t wm_dwconv_bwd_scratch_floats(int32_t B, int32_t hw, int32_t Ch) {
+  return (int64_t)B * (hw / TP) * Ch * 10;
+}
+
 extern "C" int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, void* dh1, float* dw, float* db,
-                             int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream) {
+                             float* scratch, int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream) {
   if (!h1 || !dh2 || !w || !dh1 || !dw || !db || !ok(B, hw, Ch)) return WM_EINVAL;
   const int nt = hw / TP;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (io_bf16)
     hipLaunchKernelGGL(dwconv_bwd_kernel<__bf16>, dim3(B * nt, Ch / TC), dim3(256), 0, st, static_cast<const __bf16*>(h1),
-                       static_cast<const __bf16*>(dh2), w, static_cast<__bf16*>(dh1), dw, db, B, hw, Ch);
+                       static_cast<const __bf16*>(dh2), w, static_cast<__bf16*>(dh1), dw, db, scratch, B, hw, Ch);
   else
     hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(B * nt, Ch / TC), dim3(256), 0, st, static_cast<const float*>(h1),
-                       static_cast<const float*>(dh2), w, static_cast<float*>(dh1), dw, db, B, hw, Ch);
+                       static_cast<const float*>(dh2), w, static_cast<float*>(dh1), dw, db, scratch, B, hw, Ch);
   WM_CHECK_LAUNCH();
+  if (scratch) {
+    const int P = B * nt;
+    int segs = P / 8 < 1 ? 1 : (P / 8 > 32 ? 32 : P / 8);
+    const int per = (P + segs - 1) / segs;
+    segs = (P + per - 1) / per;
+    hipLaunchKernelGGL(dwconv_grad_reduce_kernel, dim3((Ch * 10 + 255) / 256, segs), dim3(256), 0, st, scratch, dw, db, P, Ch, per);
+    WM_CHECK_LAUNCH();
+  }
   return WM_OK;
 }

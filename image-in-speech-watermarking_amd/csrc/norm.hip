@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const DT* __restrict__ dy, 
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int64_t rows) {
+                                                     float* __restrict__ dbeta, float* __restrict__ part, int64_t rows) {
   constexpr int L = (C / 4 < 64) ? C / 4 : 64;
   constexpr int V = C / (4 * L);
   constexpr int RPW = 64 / L;
@@ -147,9 +147,33 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const DT* __restrict__ dy, 
     float sg = 0.f, sb = 0.f;
 #pragma unroll
     for (int w = 0; w < LNB_WAVES; ++w) { sg += red[0][w][c]; sb += red[1][w][c]; }
-    atomicAdd(dgamma + c, sg);
-    atomicAdd(dbeta + c, sb);
+    if (part) {                                               // 512 workgroups adding into the same 2C words serialise in
+      part[(int64_t)blockIdx.x * 2 * C + c] = sg;              // the L2 atomic units: store, let ln_param_reduce_kernel sum
+      part[(int64_t)blockIdx.x * 2 * C + C + c] = sb;
+    } else {
+      atomicAdd(dgamma + c, sg);
+      atomicAdd(dbeta + c, sb);
+    }
   }
+}
+
+// dgamma[c] / dbeta[c] += sum over the P workgroups of part[p][0 / 1][c]; block (x: 256 outputs, y: segment of `per`)
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int P, int C, int per) {
+  const int i = blockIdx.x * 256 + threadIdx.x, n = 2 * C;
+  if (i >= n) return;
+  const int p0 = blockIdx.y * per, p1 = min(P, p0 + per);
+  const float* p = part + (int64_t)p0 * n + i;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int q = p0;
+  for (; q + 4 <= p1; q += 4, p += 4 * n) {
+    s0 += p[0];
+    s1 += p[n];
+    s2 += p[2 * n];
+    s3 += p[3 * n];
+  }
+  for (; q < p1; ++q, p += n) s0 += p[0];
+  atomicAdd(i < C ? dgamma + i : dbeta + (i - C), (s0 + s1) + (s2 + s3));
 }
 
 // dmod[pos, c] += sum over windows of dy[token(window, pos), c]
@@ -199,18 +223,26 @@ int ln_fwd_launch(const float* x, const float* g, const float* b, const float* m
 }
 template <int C>
 int ln_bwd_launch(const void* dy, int dy_bf16, const float* x, const float* g, const float* mean, const float* rstd,
-                  const float* dres, float* dx, float* dg, float* db, int64_t rows, hipStream_t st) {
+                  const float* dres, float* dx, float* dg, float* db, float* scratch, int64_t rows, hipStream_t st) {
   constexpr int L = (C / 4 < 64) ? C / 4 : 64;
   constexpr int RPB = LNB_WAVES * (64 / L);
   int64_t blocks = (rows + RPB - 1) / RPB;
   if (blocks > 512) blocks = 512;
   if (dy_bf16)
     hipLaunchKernelGGL((ln_bwd_kernel<C, __bf16>), dim3((unsigned)blocks), dim3(512), 0, st,
-                       static_cast<const __bf16*>(dy), x, g, mean, rstd, dres, dx, dg, db, rows);
+                       static_cast<const __bf16*>(dy), x, g, mean, rstd, dres, dx, dg, db, scratch, rows);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<C, float>), dim3((unsigned)blocks), dim3(512), 0, st,
-                       static_cast<const float*>(dy), x, g, mean, rstd, dres, dx, dg, db, rows);
+                       static_cast<const float*>(dy), x, g, mean, rstd, dres, dx, dg, db, scratch, rows);
   WM_CHECK_LAUNCH();
+  if (scratch) {
+    const int P = (int)blocks;
+    int segs = P / 8 < 1 ? 1 : (P / 8 > 32 ? 32 : P / 8);
+    const int per = (P + segs - 1) / segs;
+    segs = (P + per - 1) / per;
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 255) / 256, segs), dim3(256), 0, st, scratch, dg, db, P, C, per);
+    WM_CHECK_LAUNCH();
+  }
   return WM_OK;
 }
 
@@ -232,19 +264,22 @@ extern "C" int wm_layernorm_fwd(const float* x, const float* gamma, const float*
   }
 }
 
+extern "C" int64_t wm_layernorm_bwd_scratch_floats(int32_t C) { return 512LL * 2 * C; }
+
 extern "C" int wm_layernorm_bwd(const void* dy, int32_t dy_bf16, const float* x, const float* gamma, const float* mean,
                                 const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                                float* dmod, int64_t rows, int32_t C, int32_t hw, int32_t shift, void* stream) {
+                                float* dmod, float* scratch, int64_t rows, int32_t C, int32_t hw, int32_t shift,
+                                void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return WM_EINVAL;
   if (dmod && (hw <= 0 || (hw & 7) || rows % ((int64_t)hw * hw) || C < 64 || C > 1024)) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
   switch (C) {
-    case 32: rc = ln_bwd_launch<32>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
-    case 64: rc = ln_bwd_launch<64>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
-    case 128: rc = ln_bwd_launch<128>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
-    case 256: rc = ln_bwd_launch<256>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
-    case 512: rc = ln_bwd_launch<512>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, st); break;
+    case 32: rc = ln_bwd_launch<32>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, rows, st); break;
+    case 64: rc = ln_bwd_launch<64>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, rows, st); break;
+    case 128: rc = ln_bwd_launch<128>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, rows, st); break;
+    case 256: rc = ln_bwd_launch<256>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, rows, st); break;
+    case 512: rc = ln_bwd_launch<512>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, rows, st); break;
     default: return WM_EINVAL;
   }
   if (rc) return rc;

@@ -286,12 +286,16 @@ class UformerAudio(nn.Module):
     def _H(self, dev, *shape):
         return torch.empty(shape, device=dev, dtype=torch.bfloat16 if self.compute_mode == "bf16" else torch.float32)
 
-    def _attn_scratch(self, dev):
-        """Per-workgroup partial sums of the bias-table gradient (wm_winattn_bwd): one buffer, reused by every block."""
-        sc = getattr(self, "_attn_scr", None)
-        if sc is None or sc.device != dev:
-            sc = self._attn_scr = torch.empty(int(ops.lib.wm_winattn_bwd_scratch_floats()), device=dev)
+    def _scratch(self, dev, floats):
+        """Workspace for per-workgroup partial sums of small parameter gradients (bias table, depthwise weights): one
+        buffer, reused by every layer, grown on demand (before any graph capture: the eager warm-up sizes it)."""
+        sc = getattr(self, "_scr", None)
+        if sc is None or sc.device != dev or sc.numel() < floats:
+            sc = self._scr = torch.empty(int(floats), device=dev)
         return sc
+
+    def _attn_scratch(self, dev):
+        return self._scratch(dev, ops.lib.wm_winattn_bwd_scratch_floats())
 
     def _refresh_weight_copy(self):
         if self.compute_mode != "bf16":
@@ -401,13 +405,15 @@ class UformerAudio(nn.Module):
                               kscale=s2, k_per_scale=N)
         dh1 = H(dev, M, 4 * C)
         ops.dwconv_bwd(h1, dh2, P[pre + "mlp.dwconv.0.weight"], dh1, G[pre + "mlp.dwconv.0.weight"],
-                       G[pre + "mlp.dwconv.0.bias"], B, hw, 4 * C)
+                       G[pre + "mlp.dwconv.0.bias"], B, hw, 4 * C,
+                       scratch=self._scratch(dev, ops.lib.wm_dwconv_bwd_scratch_floats(B, hw, 4 * C)))
         dxn2 = H(dev, M, C)
         ops.linear_bwd_input(dh1, W(pre + "mlp.linear1.0.weight"), dxn2, mode)
         ops.linear_bwd_weight(dh1, xn2, G[pre + "mlp.linear1.0.weight"], G[pre + "mlp.linear1.0.bias"], mode)
         dx1 = _E(dev, M, C)
         ops.layernorm_bwd(dxn2, x1, P[pre + "norm2.weight"], mean2, rstd2, dy, dx1, G[pre + "norm2.weight"],
-                          G[pre + "norm2.bias"], None, hw, 0)
+                          G[pre + "norm2.bias"], None, hw, 0,
+                          scratch=self._scratch(dev, ops.lib.wm_layernorm_bwd_scratch_floats(C)))
         # attention
         do = dxn2                                                  # reuse buffer
         ops.linear_bwd_input(dx1, W(pre + "attn.proj.weight"), do, mode, rowscale=s1, rows_per_scale=N)
@@ -421,7 +427,8 @@ class UformerAudio(nn.Module):
         ops.linear_bwd_weight(dqkv, xn1, G[pre + "attn.qkv.w"], G[pre + "attn.qkv.b"], mode)
         dx = _E(dev, M, C)
         ops.layernorm_bwd(dxn1, x, P[pre + "norm1.weight"], mean1, rstd1, dx1, dx, G[pre + "norm1.weight"],
-                          G[pre + "norm1.bias"], G[pre + "modulator.weight"] if mod else None, hw, shift)
+                          G[pre + "norm1.bias"], G[pre + "modulator.weight"] if mod else None, hw, shift,
+                          scratch=self._scratch(dev, ops.lib.wm_layernorm_bwd_scratch_floats(C)))
         return dx
 
     def _down_fwd(self, pre, x, B, hw, C):

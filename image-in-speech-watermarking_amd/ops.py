@@ -67,10 +67,13 @@ def layernorm_fwd(x, gamma, beta, mod, y, mean, rstd, hw, shift):
                                hw, shift, _stream()), "wm_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dmod, hw, shift):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dmod, hw, shift, scratch=None):
     rows, Cc = x.shape
+    if scratch is not None and scratch.numel() < lib.wm_layernorm_bwd_scratch_floats(Cc):
+        raise ValueError("layernorm_bwd: scratch buffer too small")
     check(lib.wm_layernorm_bwd(ptr(dy), _bf(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
-                               ptr(dgamma), ptr(dbeta), ptr(dmod), rows, Cc, hw, shift, _stream()), "wm_layernorm_bwd")
+                               ptr(dgamma), ptr(dbeta), ptr(dmod), ptr(scratch), rows, Cc, hw, shift, _stream()),
+          "wm_layernorm_bwd")
 
 
 def winattn_fwd(qkv, table, out, B, hw, Cc, shift, mode, lse=None):
@@ -98,11 +101,13 @@ def dwconv_fwd(h1, w, b, h2, B, hw, Ch, a2=None, g2=None):
           "wm_dwconv_fwd")
 
 
-def dwconv_bwd(h1, dh2, w, dh1, dw, db, B, hw, Ch):
+def dwconv_bwd(h1, dh2, w, dh1, dw, db, B, hw, Ch, scratch=None):
     if not (_bf(h1) == _bf(dh2) == _bf(dh1)):
         raise ValueError("dwconv_bwd: h1, dh2 and dh1 must share a storage type")
-    check(lib.wm_dwconv_bwd(ptr(h1), ptr(dh2), ptr(w), ptr(dh1), ptr(dw), ptr(db), _bf(h1), B, hw, Ch, _stream()),
-          "wm_dwconv_bwd")
+    if scratch is not None and scratch.numel() < lib.wm_dwconv_bwd_scratch_floats(B, hw, Ch):
+        raise ValueError("dwconv_bwd: scratch buffer too small")
+    check(lib.wm_dwconv_bwd(ptr(h1), ptr(dh2), ptr(w), ptr(dh1), ptr(dw), ptr(db), ptr(scratch), _bf(h1), B, hw, Ch,
+                            _stream()), "wm_dwconv_bwd")
 
 
 def im2col(x, cols, B, hw, Cc):

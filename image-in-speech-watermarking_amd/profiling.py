@@ -37,9 +37,9 @@ COST = {
     "winattn_fwd": lambda qkv, t, o, B, hw, C, sh, mode, lse=None: (_attn_cost(B, hw, C, 2), qkv.element_size() * B * hw * hw * 4.0 * C),
     "winattn_bwd": lambda qkv, t, do, dq, dt, B, hw, C, sh, mode, out=None, lse=None, scratch=None: (_attn_cost(B, hw, C, 6), qkv.element_size() * B * hw * hw * 7.0 * C),
     "dwconv_fwd": lambda h1, w, b, h2, B, hw, Ch, a2=None, g2=None: (18.0 * B * hw * hw * Ch, (1.0 + sum(t is not None for t in (h2, a2, g2))) * h1.element_size() * B * hw * hw * Ch),
-    "dwconv_bwd": lambda h1, d, w, dh, dw, db, B, hw, Ch: (54.0 * B * hw * hw * Ch, 3.0 * h1.element_size() * B * hw * hw * Ch),
+    "dwconv_bwd": lambda h1, d, w, dh, dw, db, B, hw, Ch, scratch=None: (54.0 * B * hw * hw * Ch, 3.0 * h1.element_size() * B * hw * hw * Ch),
     "layernorm_fwd": lambda x, g, b, m, y, *a: (8.0 * x.numel(), (4.0 + y.element_size()) * x.numel()),
-    "layernorm_bwd": lambda dy, x, *a: (16.0 * x.numel(), (12.0 + dy.element_size()) * x.numel()),
+    "layernorm_bwd": lambda dy, x, *a, **k: (16.0 * x.numel(), (12.0 + dy.element_size()) * x.numel()),
     "im2col": lambda x, cols, *a: (0.0, 4.0 * (x.numel() + cols.numel())),
     "col2im": lambda dc, dx, *a: (0.0, 4.0 * (dx.numel() + dc.numel())),
     "pixel_shuffle": lambda y4, *a: (0.0, 8.0 * y4.numel()),

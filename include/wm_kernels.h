@@ -56,10 +56,13 @@ int wm_gemm(const WmGemm* g, void* stream);
 int wm_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* modulator,
                      void* y, int32_t y_bf16, float* mean, float* rstd, int64_t rows, int32_t C, int32_t hw,
                      int32_t shift, void* stream);
-/* dx = dres + LN'(dy); dgamma/dbeta atomically accumulated; dmod[64,C] accumulated if not NULL */
+/* dx = dres + LN'(dy); dgamma/dbeta accumulated; dmod[64,C] accumulated if not NULL.
+ * scratch (optional, device, >= wm_layernorm_bwd_scratch_floats(C) floats, contents irrelevant): per-workgroup partial
+ * sums of dgamma / dbeta, reduced by a second kernel; NULL = every workgroup adds with global atomics (slower).   */
+int64_t wm_layernorm_bwd_scratch_floats(int32_t C);
 int wm_layernorm_bwd(const void* dy, int32_t dy_bf16, const float* x, const float* gamma, const float* mean,
                      const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                     float* dmod, int64_t rows, int32_t C, int32_t hw, int32_t shift, void* stream);
+                     float* dmod, float* scratch, int64_t rows, int32_t C, int32_t hw, int32_t shift, void* stream);
 
 /* ---- 8x8 window attention — model.py:523-551 with roll/partition/reverse (:987-1013) and the
  * shift mask (:954-972) folded into the indexing.  qkv: [B*hw*hw, 3C] (q|k|v), heads of 32.    */
@@ -80,8 +83,11 @@ int wm_winattn_bwd(const void* qkv, const float* bias_table, const void* out, co
  * backward) and optionally a2 = GELU(h2), the A operand of linear2.                            */
 int wm_dwconv_fwd(const void* h1, const float* w, const float* b, void* h2 /* or NULL */, void* a2 /* gelu(h2) or NULL */,
                   void* g2 /* gelu'(h2) or NULL */, int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream);
-/* dh1 = gelu'(h1) * conv^T(dh2);  dw[Ch,9], db[Ch] accumulated */
-int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, void* dh1, float* dw, float* db,
+/* dh1 = gelu'(h1) * conv^T(dh2);  dw[Ch,9], db[Ch] accumulated.
+ * scratch (optional, device, >= wm_dwconv_bwd_scratch_floats(B, hw, Ch) floats, contents irrelevant): per-workgroup
+ * partial sums of dw / db, reduced by a second kernel; NULL = every workgroup adds with global atomics (slower). */
+int64_t wm_dwconv_bwd_scratch_floats(int32_t B, int32_t hw, int32_t Ch);
+int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, void* dh1, float* dw, float* db, float* scratch,
                   int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream);
 
 /* ---- data movement for Downsample (conv4x4 s2 p1, model.py:763) / Upsample (convT2x2 s2, :789) */

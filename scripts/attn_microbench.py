@@ -53,7 +53,8 @@ for hw, C in [(128, 32), (64, 64), (32, 128), (16, 256), (16, 512)]:
         w = torch.randn(Ch, 1, 3, 3, device=dev); bb = torch.randn(Ch, device=dev)
         dw = torch.zeros_like(w); db = torch.zeros_like(bb)
         tf = timeit(lambda i: ops.dwconv_fwd(bufs[i % nr][0], w, bb, None, B, hw, Ch, a2=bufs[i % nr][1], g2=bufs[i % nr][2]), nr)
-        tb = timeit(lambda i: ops.dwconv_bwd(bufs[i % nr][0], bufs[i % nr][3], w, bufs[i % nr][4], dw, db, B, hw, Ch), nr)
+        scr = torch.empty(B * (hw // 8) * Ch * 10, device=dev) if os.environ.get("SCRATCH", "1") == "1" else None
+        tb = timeit(lambda i: ops.dwconv_bwd(bufs[i % nr][0], bufs[i % nr][3], w, bufs[i % nr][4], dw, db, B, hw, Ch, scratch=scr), nr)
         byf, byb = M * Ch * 2 * 3, M * Ch * 2 * 3
         print(f"dwconv hw={hw:3d} Ch={Ch:4d} fwd {tf:7.1f} us {byf/tf/1e3:7.1f} GB/s | bwd {tb:7.1f} us {byb/tb/1e3:7.1f} GB/s", flush=True)
         del bufs
@@ -65,8 +66,9 @@ for hw, C in [(128, 32), (64, 64), (32, 128), (16, 256), (16, 512)]:
                          torch.randn(M, C, device=dev).to(bf), torch.empty(M, C, device=dev)))
         gam = torch.randn(C, device=dev); bet = torch.randn(C, device=dev)
         dg = torch.zeros(C, device=dev); dbt = torch.zeros(C, device=dev)
+        scr = torch.empty(1024 * C, device=dev) if os.environ.get("SCRATCH", "1") == "1" else None
         tf = timeit(lambda i: ops.layernorm_fwd(bufs[i % nr][0], gam, bet, None, bufs[i % nr][1], bufs[i % nr][2], bufs[i % nr][3], hw, 0), nr)
-        tb = timeit(lambda i: ops.layernorm_bwd(bufs[i % nr][4], bufs[i % nr][0], gam, bufs[i % nr][2], bufs[i % nr][3], None, bufs[i % nr][5], dg, dbt, None, hw, 0), nr)
+        tb = timeit(lambda i: ops.layernorm_bwd(bufs[i % nr][4], bufs[i % nr][0], gam, bufs[i % nr][2], bufs[i % nr][3], None, bufs[i % nr][5], dg, dbt, None, hw, 0, scratch=scr), nr)
         byf, byb = M * C * 6, M * C * 10
         print(f"ln hw={hw:3d} C={C:3d} fwd {tf:7.1f} us {byf/tf/1e3:7.1f} GB/s | bwd {tb:7.1f} us {byb/tb/1e3:7.1f} GB/s", flush=True)
         del bufs

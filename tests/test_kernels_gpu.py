@@ -128,6 +128,12 @@ def test_layernorm_fwd_bwd(wm, C):
     assert_close(db, beta.grad, 1e-4, "ln dbeta")
     if use_mod:
         assert_close(dm, mod.grad, 1e-4, "ln dmod")
+    # with a scratch buffer dgamma / dbeta are reduced by a second kernel instead of global atomics
+    scr = torch.empty(int(wm.lib.wm_layernorm_bwd_scratch_floats(C)), device="cuda")
+    dg2, db2 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    ops.layernorm_bwd(dev(dy), xd, gd, mean, rstd, dev(dres), dx, dg2, db2, None, hw, shift, scratch=scr)
+    assert_close(dg2, gamma.grad, 1e-4, "ln dgamma (scratch)")
+    assert_close(db2, beta.grad, 1e-4, "ln dbeta (scratch)")
 
 
 # ----------------------------------------------------------------------------- window attention
@@ -204,6 +210,12 @@ def test_dwconv_fwd_bwd(wm, hw, Ch):
     assert_close(dh1, h1.grad, 1e-4, "dwconv dh1")
     assert_close(dwg, w.grad.reshape(Ch, 9), 1e-4, "dwconv dw")
     assert_close(dbg, b.grad, 1e-4, "dwconv db")
+    # with a scratch buffer the weight / bias gradients are reduced by a second kernel instead of global atomics
+    scr = torch.empty(int(wm.lib.wm_dwconv_bwd_scratch_floats(B, hw, Ch)), device="cuda")
+    dwg2, dbg2 = torch.zeros_like(dwg), torch.zeros_like(dbg)
+    ops.dwconv_bwd(hd, dev(g), wd, dh1, dwg2, dbg2, B, hw, Ch, scratch=scr)
+    assert_close(dwg2, w.grad.reshape(Ch, 9), 1e-4, "dwconv dw (scratch)")
+    assert_close(dbg2, b.grad, 1e-4, "dwconv db (scratch)")
 
 
 # --------------------------------------------------------------- down / up sampling data movement
