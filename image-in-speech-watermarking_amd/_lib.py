@@ -25,7 +25,7 @@ class WmGemm(C.Structure):
                 ("b_ones", c_i32), ("C2", c_f),
                 ("atomic_out", c_i32), ("ksplit", c_i32), ("mode", c_i32),
                 ("a_bf16", c_i32), ("b_bf16", c_i32), ("c_bf16", c_i32), ("gaux_bf16", c_i32),
-                ("gaux_raw", c_i32)]
+                ("gaux_raw", c_i32), ("scratch", c_f), ("scratch_floats", c_i64)]
 
 
 class WmConv(C.Structure):
@@ -40,6 +40,7 @@ class WmAttack(C.Structure):
 
 _SIGS = {
     "wm_abi_version": [],
+    "wm_gemm_scratch_floats": [],
     "wm_gemm": [C.POINTER(WmGemm), c_f],
     "wm_layernorm_fwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f],
     "wm_layernorm_bwd_scratch_floats": [c_i32],

@@ -61,72 +61,105 @@ template <> struct Chunk<float> {
   }
 };
 
+// Operand staging.  The k loop of both kernels spent more cycles issuing address arithmetic, bounds clamps and
+// zero-selects (~240 VALU instructions per tile and thread) than MFMAs, so the per-tile work is reduced to
+// "load through a pointer, bump the pointer": `load_full` / `store_full` touch no bounds at all and are used for every
+// tile that lies completely inside K; only the last (partial) tile of a K range and workgroups on the M / N edge of the
+// matrix take the `*_tail` / `edge` variants.  Nothing may READ a loaded register before the MFMAs of the current tile
+// (not even to zero it): that would make the compiler wait for the data first, i.e. no overlap.
+
 // [R rows][BK] tile of a K-contiguous operand -> LDS [R][BK + 8]
 template <typename ST, int R, int BK, bool GELU> struct KcStage {
   static constexpr int E = Chunk<ST>::E, CPR = BK / E, RPP = 256 / CPR, NP = R / RPP, LD = BK + 8;
   static_assert(R % RPP == 0, "tile rows must be a multiple of the rows covered per pass");
-  const ST* base[NP];
+  const ST* ptr[NP];                                         // this thread's chunk of the NEXT tile to load
   Chunk<ST> c[NP];
   uint32_t rowok;
-  int kq, r0;
-  __device__ __forceinline__ void init(const void* p, int64_t ld, int row0, int rmax, int tid) {
-    r0 = tid / CPR; kq = E * (tid % CPR); rowok = 0;
+  int kq, soff;
+  bool edge;                                                 // some row of this workgroup's tile is outside the matrix
+  __device__ __forceinline__ void init(const void* p, int64_t ld, int row0, int rmax, int k0, int tid) {
+    const int r0 = tid / CPR;
+    kq = E * (tid % CPR); rowok = 0; soff = r0 * LD + kq;
+    edge = row0 + R > rmax;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       const int row = row0 + r0 + RPP * q;
       if (row < rmax) rowok |= 1u << q;
-      base[q] = static_cast<const ST*>(p) + (int64_t)min(row, rmax - 1) * ld;
+      ptr[q] = static_cast<const ST*>(p) + (int64_t)min(row, rmax - 1) * ld + k0 + kq;
     }
   }
-  __device__ __forceinline__ void load(int k0, int kend) {
-    const bool kok = k0 + kq < kend;
-    const int ko = kok ? k0 + kq : 0;
+  __device__ __forceinline__ void load_full() {
 #pragma unroll
-    for (int q = 0; q < NP; ++q) c[q].ld(base[q] + ko);
-#pragma unroll
-    for (int q = 0; q < NP; ++q) c[q].zero_if(!kok || !((rowok >> q) & 1));
+    for (int q = 0; q < NP; ++q) { c[q].ld(ptr[q]); ptr[q] += BK; }
   }
-  __device__ __forceinline__ void store(__bf16* s) const {
+  __device__ __forceinline__ void load_tail(int k0, int kend) {       // K % 8 == 0: a chunk is inside or outside
+    const int back = k0 + kq < kend ? 0 : k0 + kq;                   // outside: re-read column 0 (valid memory), zeroed at store
 #pragma unroll
-    for (int q = 0; q < NP; ++q) c[q].template st<GELU>(s + (r0 + RPP * q) * LD + kq, 1.f, false);
+    for (int q = 0; q < NP; ++q) c[q].ld(ptr[q] - back);
+  }
+  __device__ __forceinline__ void store_full(__bf16* s) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      if (edge) c[q].zero_if(!((rowok >> q) & 1));
+      c[q].template st<GELU>(s + soff + RPP * q * LD, 1.f, false);
+    }
+  }
+  __device__ __forceinline__ void store_tail(__bf16* s, int k0, int kend) {
+    const bool kok = k0 + kq < kend;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      c[q].zero_if(!kok || !((rowok >> q) & 1));
+      c[q].template st<GELU>(s + soff + RPP * q * LD, 1.f, false);
+    }
   }
 };
 
 // [KT k-rows][R columns] tile of a row-contiguous operand -> LDS [KT][R + 32] (as it lies)
 template <typename ST, int R, int KT, bool GELU> struct TrStage {
-  static constexpr int E = Chunk<ST>::E, CPR = R / E, NCH = KT * CPR, NP = NCH / 256, LD = R + 32;
-  static_assert(NCH % 256 == 0, "tile must be a multiple of 256 chunks");
-  const ST* base[NP];
+  static constexpr int E = Chunk<ST>::E, CPR = R / E, NCH = KT * CPR, NP = NCH / 256, RPQ = 256 / CPR, LD = R + 32;
+  static_assert(NCH % 256 == 0 && 256 % CPR == 0, "tile must be a multiple of 256 chunks");
+  const ST* ptr[NP];                                         // this thread's chunk (row kr + RPQ q, fixed column) of the next tile
   Chunk<ST> c[NP];
-  uint32_t colok;
-  int64_t ld;
-  __device__ __forceinline__ void init(const void* p, int64_t ld_, int c0, int cmax, int tid) {
-    ld = ld_; colok = 0;
+  float sc;                                                  // per-tile scale on A (DropPath keep factor of the tile's sample)
+  int64_t ld, step;
+  int kr, soff;
+  bool colok, edge;
+  __device__ __forceinline__ void init(const void* p, int64_t ld_, int c0, int cmax, int k0, int tid) {
+    ld = ld_; step = (int64_t)KT * ld_; sc = 1.f;
+    kr = tid / CPR;
+    const int col = c0 + E * (tid % CPR);
+    colok = col < cmax;                                      // cmax is a multiple of E (checked on the host)
+    edge = c0 + R > cmax;
+    soff = kr * LD + E * (tid % CPR);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) ptr[q] = static_cast<const ST*>(p) + (int64_t)(k0 + kr + RPQ * q) * ld_ + min(col, cmax - E);
+  }
+  __device__ __forceinline__ void load_full() {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { c[q].ld(ptr[q]); ptr[q] += step; }
+  }
+  __device__ __forceinline__ void load_tail(int k0, int kend) {       // rows at or beyond kend re-read row kend - 1
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const int col = c0 + E * ((tid + 256 * q) % CPR);
-      if (col < cmax) colok |= 1u << q;                    // cmax is a multiple of E (checked on the host)
-      base[q] = static_cast<const ST*>(p) + min(col, cmax - E);
+      const int over = k0 + kr + RPQ * q - (kend - 1);
+      c[q].ld(ptr[q] - (over > 0 ? over : 0) * ld);
     }
   }
-  __device__ __forceinline__ void load(int k0, int kend, int tid) {
+  // kscale[k / kps] is constant over a tile when kps % KT == 0 and the K range starts on a tile boundary (checked by the
+  // caller): one scalar load per tile instead of a division per chunk
+  __device__ __forceinline__ void load_scale(const float* kscale, int kps, int k0) { sc = kscale[k0 / kps]; }
+  __device__ __forceinline__ void store_full(__bf16* s, bool scaled) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const int k = k0 + (tid + 256 * q) / CPR;
-      c[q].ld(base[q] + (int64_t)min(k, kend - 1) * ld);
-    }
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      const int k = k0 + (tid + 256 * q) / CPR;
-      c[q].zero_if(k >= kend || !((colok >> q) & 1));
+      if (edge) c[q].zero_if(!colok);
+      c[q].template st<GELU>(s + soff + RPQ * q * LD, sc, scaled);
     }
   }
-  __device__ __forceinline__ void store(__bf16* s, const float* kscale, int kps, int k0, int tid) const {
+  __device__ __forceinline__ void store_tail(__bf16* s, bool scaled, int k0, int kend) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const int ch = tid + 256 * q, kr = ch / CPR;
-      const float sc = kscale ? kscale[(k0 + kr) / kps] : 1.f;
-      c[q].template st<GELU>(s + kr * LD + E * (ch % CPR), sc, kscale != nullptr);
+      c[q].zero_if(k0 + kr + RPQ * q >= kend || !colok);
+      c[q].template st<GELU>(s + soff + RPQ * q * LD, sc, scaled);
     }
   }
 };
@@ -166,43 +199,66 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemm g, const bool
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   KcStage<AT, BM, BK, A_GELU> sa;
-  sa.init(g.A, g.lda, m0, g.M, tid);
+  sa.init(g.A, g.lda, m0, g.M, 0, tid);
   KcStage<BT, BN, BK, false> sbk;
   TrStage<BT, BN, BK, false> sbt;
-  if constexpr (B_TR) sbt.init(g.B, g.ldb, n0, g.N, tid); else sbk.init(g.B, g.ldb, n0, g.N, tid);
+  if constexpr (B_TR) sbt.init(g.B, g.ldb, n0, g.N, 0, tid); else sbk.init(g.B, g.ldb, n0, g.N, 0, tid);
 
-  sa.load(0, K);
-  if constexpr (B_TR) sbt.load(0, K, tid); else sbk.load(0, K);
-  sa.store(As);
-  if constexpr (B_TR) sbt.store(Bs, nullptr, 1, 0, tid); else sbk.store(Bs);
+  const int nfull = K / BK, ntiles = (K + BK - 1) / BK;     // tiles [0, nfull) lie completely inside K
+  if (nfull > 0) {
+    sa.load_full();
+    if constexpr (B_TR) sbt.load_full(); else sbk.load_full();
+    sa.store_full(As);
+    if constexpr (B_TR) sbt.store_full(Bs, false); else sbk.store_full(Bs);
+  } else {
+    sa.load_tail(0, K);
+    if constexpr (B_TR) sbt.load_tail(0, K); else sbk.load_tail(0, K);
+    sa.store_tail(As, 0, K);
+    if constexpr (B_TR) sbt.store_tail(Bs, false, 0, K); else sbk.store_tail(Bs, 0, K);
+  }
   __syncthreads();
   int buf = 0;
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    const bool more = k0 + BK < K;
-    if (more) {
-      sa.load(k0 + BK, K);
-      if constexpr (B_TR) sbt.load(k0 + BK, K, tid); else sbk.load(k0 + BK, K);
+  for (int t = 0; t < ntiles; ++t) {
+    const int nx = t + 1;
+    if (nx < nfull) {
+      sa.load_full();
+      if constexpr (B_TR) sbt.load_full(); else sbk.load_full();
+    } else if (nx < ntiles) {
+      sa.load_tail(nx * BK, K);
+      if constexpr (B_TR) sbt.load_tail(nx * BK, K); else sbk.load_tail(nx * BK, K);
     }
     const __bf16* Ab = As + buf * BM * LDA + ((wm * TM) * 32 + r) * LDA;
     const __bf16* Bb = Bs + buf * BSZ;
+    // operand fragments of k-step ks + 1 are read from LDS while the MFMAs of step ks run (at one or two waves per SIMD
+    // nothing else hides the LDS latency: waiting for each step's reads in turn parked the wave ~40 % of the loop)
+    bf16x8 a[2][TM], b[2][TN];
+    auto frags = [&](int ks, bf16x8 (&fa)[TM], bf16x8 (&fb)[TN]) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDA + 16 * ks + 8 * h);
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDA + 16 * ks + 8 * h);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if constexpr (B_TR) b[j] = tr_frag(Bb, LDB, (wn * TN + j) * 32, ks, lane);
-        else b[j] = *reinterpret_cast<const bf16x8*>(Bb + ((wn * TN + j) * 32 + r) * LDB + 16 * ks + 8 * h);
+        if constexpr (B_TR) fb[j] = tr_frag(Bb, LDB, (wn * TN + j) * 32, ks, lane);
+        else fb[j] = *reinterpret_cast<const bf16x8*>(Bb + ((wn * TN + j) * 32 + r) * LDB + 16 * ks + 8 * h);
       }
+    };
+    frags(0, a[0], b[0]);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      if (ks + 1 < BK / 16) frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);                      // keep the reads ahead of the MFMAs (the scheduler sinks them back)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) {
-      sa.store(As + (buf ^ 1) * BM * LDA);
-      if constexpr (B_TR) sbt.store(Bs + (buf ^ 1) * BSZ, nullptr, 1, k0 + BK, tid); else sbk.store(Bs + (buf ^ 1) * BSZ);
+    if (nx < nfull) {
+      sa.store_full(As + (buf ^ 1) * BM * LDA);
+      if constexpr (B_TR) sbt.store_full(Bs + (buf ^ 1) * BSZ, false); else sbk.store_full(Bs + (buf ^ 1) * BSZ);
+    } else if (nx < ntiles) {
+      sa.store_tail(As + (buf ^ 1) * BM * LDA, nx * BK, K);
+      if constexpr (B_TR) sbt.store_tail(Bs + (buf ^ 1) * BSZ, false, nx * BK, K); else sbk.store_tail(Bs + (buf ^ 1) * BSZ, nx * BK, K);
     }
     __syncthreads();
     buf ^= 1;
@@ -269,11 +325,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemm g, const bool
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int TBK = 32;                                    // k rows per tile of the weight-gradient kernel
+constexpr int TBK = 64;                                    // k rows per tile of the weight-gradient kernel (32 KB of loads in flight per workgroup)
 
 template <typename AT, typename BT, bool B_GELU, int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int klen, const int tiles_n, const int tiles_m,
-                                                      const int ksplit) {
+                                                      const int ksplit, float* __restrict__ part) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 32, LDB = BN + 32;
   __shared__ __attribute__((aligned(16))) __bf16 As[2][TBK * LDA];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TBK * LDB];
@@ -287,7 +343,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int 
   }
   const int m0 = by * BM, n0 = bx * BN;
   const int kbeg = bz * klen, kend = min(g.K, kbeg + klen);
-  const bool do_bias = g.b_ones && bx == 0;
+  // Bias gradient = column sums of A over this K range.  They do not depend on the N tile, so the k rows of every
+  // staged A tile are dealt out over the tiles_n workgroups that hold it (and over the 256 / BM thread groups of each):
+  // having the bx == 0 workgroups sum all 64 rows alone made them the stragglers of the launch (~1 us per k tile).
+  const int bias_step = tiles_n * (256 / BM), bias_first = bx * (256 / BM) + tid / BM;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -300,56 +359,93 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int 
 
   TrStage<AT, BM, TBK, false> sa;
   TrStage<BT, BN, TBK, B_GELU> sb;
-  sa.init(g.A, g.lda, m0, g.M, tid);
-  sb.init(g.B, g.ldb, n0, g.N, tid);
-  sa.load(kbeg, kend, tid);
-  sb.load(kbeg, kend, tid);
-  sa.store(As[0], g.kscale, g.k_per_scale, kbeg, tid);
-  sb.store(Bs[0], nullptr, 1, kbeg, tid);
+  sa.init(g.A, g.lda, m0, g.M, kbeg, tid);
+  sb.init(g.B, g.ldb, n0, g.N, kbeg, tid);
+  const bool scaled = g.kscale != nullptr;                   // host guarantees k_per_scale % TBK == 0 and klen % TBK == 0
+  const int nfull = (kend - kbeg) / TBK, ntiles = (kend - kbeg + TBK - 1) / TBK;
+  if (scaled) sa.load_scale(g.kscale, g.k_per_scale, kbeg);
+  if (nfull > 0) {
+    sa.load_full(); sb.load_full();
+    sa.store_full(As[0], scaled); sb.store_full(Bs[0], false);
+  } else {
+    sa.load_tail(kbeg, kend); sb.load_tail(kbeg, kend);
+    sa.store_tail(As[0], scaled, kbeg, kend); sb.store_tail(Bs[0], false, kbeg, kend);
+  }
   __syncthreads();
   int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += TBK) {
-    const bool more = k0 + TBK < kend;
-    if (more) {
-      sa.load(k0 + TBK, kend, tid);
-      sb.load(k0 + TBK, kend, tid);
-    }
+  for (int t = 0; t < ntiles; ++t) {
+    const int nx = t + 1, kn = kbeg + nx * TBK;
+    if (nx < ntiles && scaled) sa.load_scale(g.kscale, g.k_per_scale, kn);
+    if (nx < nfull) { sa.load_full(); sb.load_full(); }
+    else if (nx < ntiles) { sa.load_tail(kn, kend); sb.load_tail(kn, kend); }
+    bf16x8 a[2][TM], b[2][TN];                              // fragments of step ks + 1 are read while step ks multiplies
+    auto frags = [&](int ks, bf16x8 (&fa)[TM], bf16x8 (&fb)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = tr_frag(As[buf], LDA, (wm * TM + i) * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = tr_frag(Bs[buf], LDB, (wn * TN + j) * 32, ks, lane);
+    };
+    frags(0, a[0], b[0]);
 #pragma unroll
     for (int ks = 0; ks < TBK / 16; ++ks) {
-      bf16x8 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = tr_frag(As[buf], LDA, (wm * TM + i) * 32, ks, lane);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = tr_frag(Bs[buf], LDB, (wn * TN + j) * 32, ks, lane);
+      if (ks + 1 < TBK / 16) frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);                      // keep the reads ahead of the MFMAs (the scheduler sinks them back)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (do_bias && tid < BM) {
-#pragma unroll 8
-      for (int kr = 0; kr < TBK; ++kr) bsum += (float)As[buf][kr * LDA + tid];
+    if (g.b_ones) {                                            // column sums of A (bias gradient), see bias_first above
+#pragma unroll 4
+      for (int kr = bias_first; kr < TBK; kr += bias_step) bsum += (float)As[buf][kr * LDA + (tid & (BM - 1))];
     }
-    if (more) {
-      sa.store(As[buf ^ 1], g.kscale, g.k_per_scale, k0 + TBK, tid);
-      sb.store(Bs[buf ^ 1], nullptr, 1, k0 + TBK, tid);
-    }
+    if (nx < nfull) { sa.store_full(As[buf ^ 1], scaled); sb.store_full(Bs[buf ^ 1], false); }
+    else if (nx < ntiles) { sa.store_tail(As[buf ^ 1], scaled, kn, kend); sb.store_tail(Bs[buf ^ 1], false, kn, kend); }
     __syncthreads();
     buf ^= 1;
   }
   float* C = static_cast<float*>(g.C);
+  const int how = part ? 0 : (ksplit == 1 ? 1 : 2);
+  float* const dst = part ? part + (int64_t)bz * g.M * g.N : C;
+  const int64_t ldd = part ? g.N : g.ldc;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + (wn * TN + j) * 32 + r;
+      float old[16];
+      if (how == 1) {                                         // all 16 reads in flight before the first add
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = min(m0 + (wm * TM + i) * 32 + mma32_row(e, h), g.M - 1);
+          old[e] = dst[m * ldd + min(n, g.N - 1)];
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + (wm * TM + i) * 32 + mma32_row(e, h);
-        if (m < g.M && n < g.N) atomicAdd(C + (int64_t)m * g.ldc + n, acc[i][j][e]);
+        if (m < g.M && n < g.N) {
+          float* d = dst + m * ldd + n;
+          if (how == 0) *d = acc[i][j][e];
+          else if (how == 1) *d = old[e] + acc[i][j][e];
+          else atomicAdd(d, acc[i][j][e]);
+        }
       }
     }
-  if (do_bias && tid < BM && m0 + tid < g.M) atomicAdd(g.C2 + m0 + tid, bsum);
+  if (g.b_ones) {                                              // fold the thread groups through LDS: one atomic per column
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&As[0][0]);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < BM && m0 + tid < g.M) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 256 / BM; ++q) t += red[q * BM + tid];
+      atomicAdd(g.C2 + m0 + tid, t);
+    }
+  }
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -386,27 +482,70 @@ int dispatch_nt(const WmGemm& g, hipStream_t st) {
   return launch_nt<AT, BT, B_TR, A_GELU, 2, 2, 1, 1>(g, st);                           // 64 x 64
 }
 
+// C[m][n] += sum over z in this block's segment of part[z][m][n]; thread = 4 consecutive n (N % 4 == 0)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, int64_t ldc,
+                                                            int M, int N, int ksplit, int per) {
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x, mn = (int64_t)M * N;
+  if (i4 * 4 >= mn) return;
+  const int z0 = blockIdx.y * per, z1 = min(ksplit, z0 + per);
+  const float* p = part + z0 * mn + i4 * 4;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  int z = z0;
+  for (; z + 2 <= z1; z += 2, p += 2 * mn) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + mn);
+    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+  }
+  if (z < z1) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+  }
+  const int m = (int)(i4 * 4 / N), n = (int)(i4 * 4 - (int64_t)m * N);
+  float* c = C + m * ldc + n;
+  if (gridDim.y == 1) {
+    c[0] += s0.x + s1.x; c[1] += s0.y + s1.y; c[2] += s0.z + s1.z; c[3] += s0.w + s1.w;
+  } else {
+    atomicAdd(c + 0, s0.x + s1.x); atomicAdd(c + 1, s0.y + s1.y); atomicAdd(c + 2, s0.z + s1.z); atomicAdd(c + 3, s0.w + s1.w);
+  }
+}
+
 template <typename AT, typename BT, bool B_GELU, int TM, int TN>
 int launch_tn(const WmGemm& g, hipStream_t st) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
-  int ksplit = g.ksplit > 0 ? g.ksplit : (768 + tiles - 1) / tiles;
-  const int maxs = (g.K + 255) / 256;
+  const int64_t mn = (int64_t)g.M * g.N;
+  const bool use_part = g.scratch && !(g.N & 3);
+  int ksplit = g.ksplit > 0 ? g.ksplit : ((use_part ? 384 : 768) + tiles - 1) / tiles;
+  const int maxs = (g.K + (use_part ? 127 : 255)) / (use_part ? 128 : 256);
   if (ksplit > maxs) ksplit = maxs;
+  if (use_part && (int64_t)ksplit * mn > g.scratch_floats) ksplit = (int)(g.scratch_floats / mn);
   if (ksplit < 1) ksplit = 1;
   int klen = (g.K + ksplit - 1) / ksplit;
   klen = (klen + TBK - 1) / TBK * TBK;
   ksplit = (g.K + klen - 1) / klen;
+  float* part = (use_part && ksplit > 1) ? g.scratch : nullptr;
   hipLaunchKernelGGL((gemm_tn_kernel<AT, BT, B_GELU, TM, TN>), dim3(8 * ((ksplit + 7) / 8) * tiles), dim3(256), 0, st, g, klen,
-                     tiles_n, tiles_m, ksplit);
+                     tiles_n, tiles_m, ksplit, part);
   WM_CHECK_LAUNCH();
+  if (part) {
+    const int64_t blocks = (mn / 4 + 255) / 256;
+    int segs = (int)(256 / blocks);
+    if (segs > ksplit / 4) segs = ksplit / 4;
+    if (segs < 1) segs = 1;
+    const int per = (ksplit + segs - 1) / segs;
+    segs = (ksplit + per - 1) / per;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks, segs), dim3(256), 0, st, part, static_cast<float*>(g.C), g.ldc,
+                       g.M, g.N, ksplit, per);
+    WM_CHECK_LAUNCH();
+  }
   return WM_OK;
 }
 
 template <typename AT, typename BT, bool B_GELU>
 int dispatch_tn(const WmGemm& g, hipStream_t st) {
-  if (g.M > 64 && g.N > 64) return launch_tn<AT, BT, B_GELU, 2, 2>(g, st);
-  if (g.M > 64) return launch_tn<AT, BT, B_GELU, 2, 1>(g, st);
+  const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  if (g.M > 64 && g.N > 64 && (t128 >= 8 || !g.scratch)) return launch_tn<AT, BT, B_GELU, 2, 2>(g, st);
+  if (g.M > 64 && (g.N <= 64 || t128 >= 2)) return launch_tn<AT, BT, B_GELU, 2, 1>(g, st);
   return launch_tn<AT, BT, B_GELU, 1, 1>(g, st);
 }
 
@@ -418,6 +557,7 @@ int wm_gemm_fast_bf16(const WmGemm& g, hipStream_t st) {
   const int ea = g.a_bf16 ? 8 : 4, eb = g.b_bf16 ? 8 : 4;
   if (!g.a_kc && !g.b_kc && g.atomic_out && !g.a_op && !g.c_bf16) {          // weight gradient
     if ((g.M % ea) || (g.N % eb) || (g.lda % ea) || (g.ldb % eb) || g.M < ea || g.N < eb) return -1;
+    if (g.kscale && (g.k_per_scale <= 0 || g.k_per_scale % TBK)) return -1;    // one scale per k tile (TrStage::load_scale)
     if (g.b_op) {
       if (g.a_bf16 && g.b_bf16) return dispatch_tn<__bf16, __bf16, true>(g, st);
       if (g.a_bf16) return dispatch_tn<__bf16, float, true>(g, st);

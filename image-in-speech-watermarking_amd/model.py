@@ -294,6 +294,9 @@ class UformerAudio(nn.Module):
             sc = self._scr = torch.empty(int(floats), device=dev)
         return sc
 
+    def _gemm_scratch(self, dev):
+        return self._scratch(dev, ops.lib.wm_gemm_scratch_floats())
+
     def _attn_scratch(self, dev):
         return self._scratch(dev, ops.lib.wm_winattn_bwd_scratch_floats())
 
@@ -402,14 +405,14 @@ class UformerAudio(nn.Module):
         dh2 = H(dev, M, 4 * C)
         ops.linear_bwd_input(dy, W(pre + "mlp.linear2.0.weight"), dh2, mode, rowscale=s2, rows_per_scale=N, gaux=h2, gaux_raw=True)
         ops.linear_bwd_weight(dy, a2, G[pre + "mlp.linear2.0.weight"], G[pre + "mlp.linear2.0.bias"], mode,
-                              kscale=s2, k_per_scale=N)
+                              kscale=s2, k_per_scale=N, scratch=self._gemm_scratch(dev))
         dh1 = H(dev, M, 4 * C)
         ops.dwconv_bwd(h1, dh2, P[pre + "mlp.dwconv.0.weight"], dh1, G[pre + "mlp.dwconv.0.weight"],
                        G[pre + "mlp.dwconv.0.bias"], B, hw, 4 * C,
                        scratch=self._scratch(dev, ops.lib.wm_dwconv_bwd_scratch_floats(B, hw, 4 * C)))
         dxn2 = H(dev, M, C)
         ops.linear_bwd_input(dh1, W(pre + "mlp.linear1.0.weight"), dxn2, mode)
-        ops.linear_bwd_weight(dh1, xn2, G[pre + "mlp.linear1.0.weight"], G[pre + "mlp.linear1.0.bias"], mode)
+        ops.linear_bwd_weight(dh1, xn2, G[pre + "mlp.linear1.0.weight"], G[pre + "mlp.linear1.0.bias"], mode, scratch=self._gemm_scratch(dev))
         dx1 = _E(dev, M, C)
         ops.layernorm_bwd(dxn2, x1, P[pre + "norm2.weight"], mean2, rstd2, dy, dx1, G[pre + "norm2.weight"],
                           G[pre + "norm2.bias"], None, hw, 0,
@@ -417,14 +420,14 @@ class UformerAudio(nn.Module):
         # attention
         do = dxn2                                                  # reuse buffer
         ops.linear_bwd_input(dx1, W(pre + "attn.proj.weight"), do, mode, rowscale=s1, rows_per_scale=N)
-        ops.linear_bwd_weight(dx1, o, G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], mode, kscale=s1, k_per_scale=N)
+        ops.linear_bwd_weight(dx1, o, G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], mode, kscale=s1, k_per_scale=N, scratch=self._gemm_scratch(dev))
         dqkv = H(dev, M, 3 * C)
         ops.winattn_bwd(qkv, P[pre + "attn.relative_position_bias_table"], do, dqkv,
                         G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, mode, out=o, lse=lse,
                         scratch=self._attn_scratch(dev))
         dxn1 = H(dev, M, C)
         ops.linear_bwd_input(dqkv, W(pre + "attn.qkv.w"), dxn1, mode)
-        ops.linear_bwd_weight(dqkv, xn1, G[pre + "attn.qkv.w"], G[pre + "attn.qkv.b"], mode)
+        ops.linear_bwd_weight(dqkv, xn1, G[pre + "attn.qkv.w"], G[pre + "attn.qkv.b"], mode, scratch=self._gemm_scratch(dev))
         dx = _E(dev, M, C)
         ops.layernorm_bwd(dxn1, x, P[pre + "norm1.weight"], mean1, rstd1, dx1, dx, G[pre + "norm1.weight"],
                           G[pre + "norm1.bias"], G[pre + "modulator.weight"] if mod else None, hw, shift,
@@ -453,7 +456,7 @@ class UformerAudio(nn.Module):
         cols = dcols
         ops.im2col(x, cols, B, hw, C)                               # recompute instead of keeping 4x the input alive
         dw2 = _Z(dev, 2 * C, 16 * C)
-        ops.linear_bwd_weight(dy, cols, dw2, G[pre + "bias"], mode)
+        ops.linear_bwd_weight(dy, cols, dw2, G[pre + "bias"], mode, scratch=self._gemm_scratch(dev))
         ops.strided3(dw2, G[pre + "weight"], (2 * C, 16, C), (16 * C, C, 1), (16 * C, 1, 16), atomic=True)
         return dx
 
@@ -481,7 +484,7 @@ class UformerAudio(nn.Module):
         dx = _E(dev, M, Cin)
         ops.linear_bwd_input(dy4, wr, dx, mode)
         dwr, db4 = _Z(dev, 4 * Co, Cin), _Z(dev, 4 * Co)
-        ops.linear_bwd_weight(dy4, x, dwr, db4, mode)
+        ops.linear_bwd_weight(dy4, x, dwr, db4, mode, scratch=self._gemm_scratch(dev))
         ops.strided3(dwr, G[pre + "weight"], (4, Co, Cin), (Co * Cin, Cin, 1), (1, 4, 4 * Co), atomic=True)
         ops.strided3(db4, G[pre + "bias"], (1, 4, Co), (0, Co, 1), (0, 0, 1), atomic=True)
         return dx, dskip

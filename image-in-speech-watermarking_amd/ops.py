@@ -30,10 +30,11 @@ def _bf(t):
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=1, b_kc=1, a_op=0, b_op=0, bias=None, res=None, ldr=0,
          rowscale=None, rows_per_scale=0, kscale=None, k_per_scale=0, gaux=None, ldg=0, b_ones=False, C2=None,
-         atomic_out=False, ksplit=0, mode=MODE_FP32, gaux_raw=False):
+         atomic_out=False, ksplit=0, mode=MODE_FP32, gaux_raw=False, scratch=None):
     g = WmGemm(ptr(A), ptr(B), ptr(Cout), M, N, K, lda, ldb, ldc, a_kc, b_kc, a_op, b_op, ptr(bias), ptr(res), ldr,
                ptr(rowscale), rows_per_scale, ptr(kscale), k_per_scale, ptr(gaux), ldg, int(b_ones), ptr(C2),
-               int(atomic_out), ksplit, mode, _bf(A), _bf(B), _bf(Cout), _bf(gaux), int(gaux_raw))
+               int(atomic_out), ksplit, mode, _bf(A), _bf(B), _bf(Cout), _bf(gaux), int(gaux_raw),
+               ptr(scratch), scratch.numel() if scratch is not None else 0)
     check(lib.wm_gemm(C.byref(g), _stream()), f"wm_gemm(M={M},N={N},K={K})")
 
 
@@ -53,12 +54,12 @@ def linear_bwd_input(dy, w, dx, mode, rowscale=None, rows_per_scale=0, gaux=None
          mode=mode, gaux_raw=gaux_raw)
 
 
-def linear_bwd_weight(dy, x, dw, db, mode, x_op=0, kscale=None, k_per_scale=0):
+def linear_bwd_weight(dy, x, dw, db, mode, x_op=0, kscale=None, k_per_scale=0, scratch=None):
     """dw[N,K] += (dy*kscale)^T[N,M] @ op(x)[M,K];  db[N] += column sums of dy*kscale"""
     M, N = dy.shape
     K = x.shape[1]
     gemm(dy, x, dw, N, K, M, N, K, K, 0, 0, b_op=x_op, kscale=kscale, k_per_scale=k_per_scale,
-         b_ones=db is not None, C2=db, atomic_out=True, mode=mode)
+         b_ones=db is not None, C2=db, atomic_out=True, mode=mode, scratch=scratch)
 
 
 def layernorm_fwd(x, gamma, beta, mod, y, mean, rstd, hw, shift):

@@ -49,7 +49,10 @@ typedef struct WmGemm {
   int32_t mode;
   int32_t a_bf16, b_bf16, c_bf16, gaux_bf16; /* storage type of A / B / C / gaux: 0 fp32, 1 bf16 (bf16 C: no atomics)   */
   int32_t gaux_raw;          /* 1: gaux already holds the factor (gelu'(h2) saved by wm_dwconv_fwd): plain multiply  */
+  float* scratch;            /* optional device workspace for split-K partial tiles (weight gradients, mode 1); NULL =  */
+  int64_t scratch_floats;    /* fp32 atomics into C.  wm_gemm_scratch_floats() is always enough; contents irrelevant    */
 } WmGemm;
+int64_t wm_gemm_scratch_floats(void);
 int wm_gemm(const WmGemm* g, void* stream);
 
 /* ---- LayerNorm (+ window modulator) — model.py:982,1017 (norm1/norm2), :996-997 (modulator) ---- */

@@ -86,6 +86,15 @@ def test_gemm_backward_layouts(wm, mode, M, N, K):
         dys = dy * rs.repeat_interleave(rows_per)[:M, None]
         assert_close(dw, dys.t() @ F.gelu(x), TOL[mode] * (3 if mode else 1), f"dW ksplit={ks}")
         assert_close(db, dys.sum(0), TOL[mode] * (3 if mode else 1), f"db ksplit={ks}")
+    # split-K through a scratch buffer (partial tiles + reduce kernel) instead of atomics; gradients ACCUMULATE into dw
+    scr = torch.empty(int(wm.lib.wm_gemm_scratch_floats()), device="cuda")
+    for ks in (0, 1, 3):
+        dw = torch.ones(N, K, device="cuda")
+        db = torch.zeros(N, device="cuda")
+        ops.gemm(dev(dy), dev(x), dw, N, K, M, N, K, K, 0, 0, b_op=1, kscale=dev(rs), k_per_scale=rows_per, b_ones=True,
+                 C2=db, atomic_out=True, ksplit=ks, mode=mode, scratch=scr)
+        assert_close(dw - 1.0, dys.t() @ F.gelu(x), TOL[mode] * (3 if mode else 1), f"dW scratch ksplit={ks}")
+        assert_close(db, dys.sum(0), TOL[mode] * (3 if mode else 1), f"db scratch ksplit={ks}")
 
 
 def test_gemm_rejects_bad_args(wm):
