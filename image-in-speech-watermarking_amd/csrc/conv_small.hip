@@ -6,6 +6,11 @@
 #include "common.h"
 #include "../../include/wm_kernels.h"
 
+// full-resolution 2 <-> 32/64 channel layers (conv_edge.hip); -1 = not such a layer
+int wm_conv_edge_fwd(const WmConv& c, const float* x, const float* w, const float* b, float* y, hipStream_t st);
+int wm_conv_edge_dx(const WmConv& c, const float* w, const float* y, const float* dy, float* dx, int accumulate,
+                    hipStream_t st);
+
 namespace {
 
 __device__ __forceinline__ float act_f(float v, int act) {
@@ -323,6 +328,8 @@ bool conv_ok(const WmConv* c) {
 
 extern "C" int wm_conv_fwd(const WmConv* c, const float* x, const float* w, const float* b, float* y, void* stream) {
   if (!conv_ok(c) || !x || !w || !y) return WM_EINVAL;
+  const int edge = wm_conv_edge_fwd(*c, x, w, b, y, static_cast<hipStream_t>(stream));
+  if (edge >= 0) return edge;
   const int64_t total = (int64_t)c->B * c->Cout * c->OH * c->OW;
   hipLaunchKernelGGL(conv_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), *c, x, w,
                      b, y, total);
@@ -335,9 +342,13 @@ extern "C" int wm_conv_bwd(const WmConv* c, const float* x, const float* w, cons
   if (!conv_ok(c) || !x || !w || !y || !dy) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dx) {
-    const int64_t total = (int64_t)c->B * c->Cin * c->H * c->W;
-    hipLaunchKernelGGL(conv_dx_kernel, dim3(grid_for(total)), dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate, total);
-    WM_CHECK_LAUNCH();
+    const int edge = wm_conv_edge_dx(*c, w, y, dy, dx, dx_accumulate, st);
+    if (edge > 0) return edge;
+    if (edge < 0) {
+      const int64_t total = (int64_t)c->B * c->Cin * c->H * c->W;
+      hipLaunchKernelGGL(conv_dx_kernel, dim3(grid_for(total)), dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate, total);
+      WM_CHECK_LAUNCH();
+    }
   }
   const bool tiled = dw && !c->transposed && c->KH == 3 && c->KW == 3 && c->SH == 1 && c->SW == 1 && c->PH == 1 &&
                      c->PW == 1 && (c->H % 8) == 0 && (c->W % 8) == 0 &&

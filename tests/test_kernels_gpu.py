@@ -296,6 +296,8 @@ CONVS = [
     # Cin, H, W, Cout, k, stride, pad, in_nhwc, out_nhwc, act, transposed
     (2, 32, 32, 32, (3, 3), (1, 1), (1, 1), False, True, "leaky", False),      # InputProj
     (64, 16, 16, 2, (3, 3), (1, 1), (1, 1), True, False, "none", False),       # OutputProj
+    (2, 16, 48, 64, (3, 3), (1, 1), (1, 1), False, True, "leaky", False),      # fan-out kernel, 64 channels, several tiles
+    (32, 24, 16, 2, (3, 3), (1, 1), (1, 1), True, False, "relu", False),       # fan-in kernel, 32 channels, activation
     (2, 24, 24, 4, (3, 3), (1, 1), (1, 1), False, False, "relu", False),       # stft_layer.0
     (1, 32, 32, 16, (3, 3), (1, 1), (1, 1), False, False, "relu", False),      # ConvAutoencoder.conv1
     (1, 64, 512, 1, (8, 8), (16, 8), (0, 0), False, False, "none", False),     # EncoderTransformerWM.conv2
