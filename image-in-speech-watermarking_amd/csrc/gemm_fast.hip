@@ -280,46 +280,86 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemm g, const bool
   const bool full = vec_ok && n + 3 < g.N;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (full && g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + n);
-  for (int rr = tid / TPRW; rr < BM; rr += RPP) {
-    const int m = m0 + rr;
-    if (m >= g.M) break;
-    float4 v = *reinterpret_cast<const float4*>(Cs + rr * LDC + 4 * c4);
-    if (full) {
-      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-      if (g.rowscale) {
-        const float sc = g.rowscale[m / g.rows_per_scale];
-        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+  if (full) {
+    // All epilogue operands of a group of rows (DropPath scale, gelu' factor, residual) are requested BEFORE the first
+    // one is used: written as one loop the compiler waited for every load in turn, ~3 round trips per row and 16 rows
+    // per thread, which dominated the short-K launches.
+    constexpr int NR = BM / RPP, G = NR < 8 ? NR : 8;
+    const int r0 = tid / TPRW;
+    const bool sc_uniform = g.rowscale && (g.rows_per_scale % BM) == 0;       // one sample per row tile
+    const float sc_tile = sc_uniform ? g.rowscale[m0 / g.rows_per_scale] : 1.f;
+#pragma unroll
+    for (int g0 = 0; g0 < NR; g0 += G) {
+      uint4 ga[G];
+      float4 re[G];
+      float sc[G];
+      int64_t mrow[G];
+#pragma unroll
+      for (int q = 0; q < G; ++q) {
+        mrow[q] = min(m0 + r0 + (g0 + q) * RPP, g.M - 1);
+        sc[q] = sc_tile;
       }
-      if (g.gaux) {
-        const float4 a = g.gaux_bf16 ? IO<__bf16>::ld4(static_cast<const __bf16*>(g.gaux) + (int64_t)m * g.ldg + n)
-                                     : IO<float>::ld4(static_cast<const float*>(g.gaux) + (int64_t)m * g.ldg + n);
-        if (g.gaux_raw) { v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w; }
-        else { v.x *= gelu_grad_f(a.x); v.y *= gelu_grad_f(a.y); v.z *= gelu_grad_f(a.z); v.w *= gelu_grad_f(a.w); }
+      // one straight-line loop per operand (a per-row if / else makes the compiler drain the loads row by row)
+      if (g.rowscale && !sc_uniform) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) sc[q] = g.rowscale[mrow[q] / g.rows_per_scale];
+      }
+      if (g.gaux && g.gaux_bf16) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+          const uint2 t = *reinterpret_cast<const uint2*>(static_cast<const __bf16*>(g.gaux) + mrow[q] * g.ldg + n);
+          ga[q] = make_uint4(t.x, t.y, 0u, 0u);
+        }
+      } else if (g.gaux) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) ga[q] = *reinterpret_cast<const uint4*>(static_cast<const float*>(g.gaux) + mrow[q] * g.ldg + n);
       }
       if (g.res) {
-        const float4 a = *reinterpret_cast<const float4*>(g.res + (int64_t)m * g.ldr + n);
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-      }
-      if (g.c_bf16) IO<__bf16>::st4(static_cast<__bf16*>(g.C) + (int64_t)m * g.ldc + n, v);
-      else IO<float>::st4(static_cast<float*>(g.C) + (int64_t)m * g.ldc + n, v);
-    } else {
-      const float e4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int nn = n + q;
-        if (nn >= g.N) continue;
-        float val = e4[q];
-        if (g.bias) val += g.bias[nn];
-        if (g.rowscale) val *= g.rowscale[m / g.rows_per_scale];
-        if (g.gaux) {
-          const float av = g.gaux_bf16 ? (float)static_cast<const __bf16*>(g.gaux)[(int64_t)m * g.ldg + nn]
-                                       : static_cast<const float*>(g.gaux)[(int64_t)m * g.ldg + nn];
-          val *= g.gaux_raw ? av : gelu_grad_f(av);
-        }
-        if (g.res) val += g.res[(int64_t)m * g.ldr + nn];
-        if (g.c_bf16) static_cast<__bf16*>(g.C)[(int64_t)m * g.ldc + nn] = (__bf16)val;
-        else static_cast<float*>(g.C)[(int64_t)m * g.ldc + nn] = val;
+        for (int q = 0; q < G; ++q) re[q] = *reinterpret_cast<const float4*>(g.res + mrow[q] * g.ldr + n);
       }
+#pragma unroll
+      for (int q = 0; q < G; ++q) {
+        const int rr = r0 + (g0 + q) * RPP, m = m0 + rr;
+        if (m < g.M) {
+          float4 v = *reinterpret_cast<const float4*>(Cs + rr * LDC + 4 * c4);
+          v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+          if (g.rowscale) { v.x *= sc[q]; v.y *= sc[q]; v.z *= sc[q]; v.w *= sc[q]; }
+          if (g.gaux) {
+            float4 a;
+            if (g.gaux_bf16) a = make_float4(bf_lo(ga[q].x), bf_hi(ga[q].x), bf_lo(ga[q].y), bf_hi(ga[q].y));
+            else a = make_float4(__uint_as_float(ga[q].x), __uint_as_float(ga[q].y), __uint_as_float(ga[q].z), __uint_as_float(ga[q].w));
+            if (g.gaux_raw) { v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w; }
+            else { v.x *= gelu_grad_f(a.x); v.y *= gelu_grad_f(a.y); v.z *= gelu_grad_f(a.z); v.w *= gelu_grad_f(a.w); }
+          }
+          if (g.res) { v.x += re[q].x; v.y += re[q].y; v.z += re[q].z; v.w += re[q].w; }
+          if (g.c_bf16) IO<__bf16>::st4(static_cast<__bf16*>(g.C) + (int64_t)m * g.ldc + n, v);
+          else IO<float>::st4(static_cast<float*>(g.C) + (int64_t)m * g.ldc + n, v);
+        }
+      }
+    }
+    return;
+  }
+  for (int rr = tid / TPRW; rr < BM; rr += RPP) {            // column-edge tiles / unaligned operands: scalar path
+    const int m = m0 + rr;
+    if (m >= g.M) break;
+    const float4 v = *reinterpret_cast<const float4*>(Cs + rr * LDC + 4 * c4);
+    const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nn = n + q;
+      if (nn >= g.N) continue;
+      float val = e4[q];
+      if (g.bias) val += g.bias[nn];
+      if (g.rowscale) val *= g.rowscale[m / g.rows_per_scale];
+      if (g.gaux) {
+        const float av = g.gaux_bf16 ? (float)static_cast<const __bf16*>(g.gaux)[(int64_t)m * g.ldg + nn]
+                                     : static_cast<const float*>(g.gaux)[(int64_t)m * g.ldg + nn];
+        val *= g.gaux_raw ? av : gelu_grad_f(av);
+      }
+      if (g.res) val += g.res[(int64_t)m * g.ldr + nn];
+      if (g.c_bf16) static_cast<__bf16*>(g.C)[(int64_t)m * g.ldc + nn] = (__bf16)val;
+      else static_cast<float*>(g.C)[(int64_t)m * g.ldc + nn] = val;
     }
   }
 }
