@@ -531,12 +531,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const float* p = part + z0 * mn + i4 * 4;
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
   int z = z0;
-  for (; z + 2 <= z1; z += 2, p += 2 * mn) {
+  for (; z + 4 <= z1; z += 4, p += 4 * mn) {                  // four slices in flight
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + mn);
-    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-    s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+    const float4 c = *reinterpret_cast<const float4*>(p + 2 * mn), d = *reinterpret_cast<const float4*>(p + 3 * mn);
+    s0.x += a.x + c.x; s0.y += a.y + c.y; s0.z += a.z + c.z; s0.w += a.w + c.w;
+    s1.x += b.x + d.x; s1.y += b.y + d.y; s1.z += b.z + d.z; s1.w += b.w + d.w;
   }
-  if (z < z1) {
+  for (; z < z1; ++z, p += mn) {
     const float4 a = *reinterpret_cast<const float4*>(p);
     s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
   }

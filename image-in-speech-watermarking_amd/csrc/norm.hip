@@ -35,13 +35,24 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const int sub = lane % L, rg = lane / L;
   const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * RPW + rg;
   if (row >= rows) return;                          // whole lane groups exit together
-  float4 v[V];
-  float s = 0.f;
+  // every global operand is requested up front (gamma / beta / modulator too): a load issued after the statistics
+  // would cost a second full memory round trip per row
+  const float* mrow = mod ? mod + (int64_t)window_pos(row, hw, shift) * C : nullptr;
+  float4 v[V], gmv[V], btv[V], mmv[V];
+#pragma unroll
+  for (int q = 0; q < V; ++q) v[q] = *reinterpret_cast<const float4*>(x + row * C + (q * L + sub) * 4);
 #pragma unroll
   for (int q = 0; q < V; ++q) {
-    v[q] = *reinterpret_cast<const float4*>(x + row * C + (q * L + sub) * 4);
-    s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+    gmv[q] = *reinterpret_cast<const float4*>(gamma + (q * L + sub) * 4);
+    btv[q] = *reinterpret_cast<const float4*>(beta + (q * L + sub) * 4);
   }
+  if (mrow) {
+#pragma unroll
+    for (int q = 0; q < V; ++q) mmv[q] = *reinterpret_cast<const float4*>(mrow + (q * L + sub) * 4);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < V; ++q) s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
   const float mu = group_sum<L>(s) * (1.0f / C);
   float ss = 0.f;
 #pragma unroll
@@ -50,21 +61,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     ss += (a * a + b * b) + (c * c + d * d);
   }
   const float rs = 1.0f / sqrtf(group_sum<L>(ss) * (1.0f / C) + LN_EPS);
-  const float* mrow = mod ? mod + (int64_t)window_pos(row, hw, shift) * C : nullptr;
 #pragma unroll
   for (int q = 0; q < V; ++q) {
     const int c = (q * L + sub) * 4;
-    const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
-    const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+    const float4 gm = gmv[q], bt = btv[q];
     float4 o;
     o.x = (v[q].x - mu) * rs * gm.x + bt.x;
     o.y = (v[q].y - mu) * rs * gm.y + bt.y;
     o.z = (v[q].z - mu) * rs * gm.z + bt.z;
     o.w = (v[q].w - mu) * rs * gm.w + bt.w;
-    if (mrow) {
-      const float4 mm = *reinterpret_cast<const float4*>(mrow + c);
-      o.x += mm.x; o.y += mm.y; o.z += mm.z; o.w += mm.w;
-    }
+    if (mrow) { o.x += mmv[q].x; o.y += mmv[q].y; o.z += mmv[q].z; o.w += mmv[q].w; }
     IO<YT>::st4(y + row * C + c, o);
   }
   if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
@@ -95,8 +101,12 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const DT* __restrict__ dy, 
   const int64_t stride = (int64_t)gridDim.x * LNB_WAVES * RPW;
   for (int64_t row = ((int64_t)blockIdx.x * LNB_WAVES + wave) * RPW + rg; row < rows; row += stride) {
     const float mu = mean[row], rs = rstd[row];
-    float4 xh[V], g[V];
+    float4 xh[V], g[V], dr[V];
     float s1 = 0.f, s2 = 0.f;
+    if (dres) {                                               // requested with the other operands, used after the reductions
+#pragma unroll
+      for (int q = 0; q < V; ++q) dr[q] = *reinterpret_cast<const float4*>(dres + row * C + (q * L + sub) * 4);
+    }
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       const int c = (q * L + sub) * 4;
@@ -119,10 +129,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const DT* __restrict__ dy, 
       o.y = rs * (g[q].y - s1 - xh[q].y * s2);
       o.z = rs * (g[q].z - s1 - xh[q].z * s2);
       o.w = rs * (g[q].w - s1 - xh[q].w * s2);
-      if (dres) {
-        const float4 dr = *reinterpret_cast<const float4*>(dres + row * C + c);
-        o.x += dr.x; o.y += dr.y; o.z += dr.z; o.w += dr.w;
-      }
+      if (dres) { o.x += dr[q].x; o.y += dr[q].y; o.z += dr[q].z; o.w += dr[q].w; }
       *reinterpret_cast<float4*>(dx + row * C + c) = o;
     }
   }
