@@ -155,6 +155,14 @@ def main():
             total = sum(r["total_s"] for r in rows)
             result["roofline"] = prof.roofline_of(rows[0])
             result["roofline"]["share_of_step_kernel_time"] = rows[0]["total_s"] / total
+            # HBM traffic per launch comes from the committed rocprofv3 PMC passes of the same workload (bench.py cannot
+            # run the profiler on itself); null when the summary is absent or was taken at another batch / mode
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_families_b{a.batch}_{a.mode}.json")
+            result["roofline"]["traffic"] = prof.pmc_traffic(rows[0]["kernel"], pmc) if not attack else None
+            result["roofline_by_kernel"] = [
+                {k: (round(v, 4) if isinstance(v, float) else v) for k, v in prof.roofline_of(r).items()
+                 if k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us")}
+                for r in rows[:8]]
             stft_rows = [r for r in rows if r["kernel"] in ("istft_fwd", "stft_fwd", "istft_bwd", "stft_bwd", "attack_fwd", "attack_bwd")]
             if stft_rows:
                 by, ts = sum(r["bytes"] for r in stft_rows), sum(r["total_s"] for r in stft_rows)

@@ -66,26 +66,16 @@ class KernelTimer:
         if name == "gemm":
             M, N, K = args[3:6]
             mode = kwargs.get("mode", 0)
-            n_eff = N + (1 if kwargs.get("b_ones") else 0)
-            cd = lambda a, b: (a + b - 1) // b
-            ks = 4 if kwargs.get("atomic_out") else 1
             a_kc = args[9] if len(args) > 9 else kwargs.get("a_kc", 1)
             b_kc = args[10] if len(args) > 10 else kwargs.get("b_kc", 1)
-            if mode == 1 and not a_kc and not b_kc and kwargs.get("atomic_out"):
-                tile = "tn_" + ("128x128" if (M > 64 and N > 64) else ("128x64" if M > 64 else "64x64"))
-            elif n_eff <= 32:
-                tile = "256x32"
-            elif n_eff > 64 and cd(M, 128) * cd(n_eff, 128) * ks >= 384:
-                tile = "128x128"
-            elif cd(M, 128) * cd(n_eff, 64) * ks >= 384 or M >= 32768:
-                tile = "128x64"
-            else:
-                tile = "64x64"                      # mirrors dispatch() in csrc/gemm.hip
+            lay = {(1, 1): "fwd", (1, 0): "dX", (0, 0): "dW"}.get((a_kc, b_kc), "?")
+            # kernel FAMILY as it appears in a rocprofv3 kernel trace: gemm_nt_kernel<...> runs forward and input-gradient
+            # GEMMs, gemm_tn_kernel<...> (+ splitk_reduce_kernel, timed together here) the weight gradients, gemm_kernel<...>
+            # is the fp32 parity-mode kernel
+            fam = "gemm_kernel(fp32)" if not mode else ("gemm_tn_kernel+splitk_reduce" if lay == "dW" else "gemm_nt_kernel")
             if self.detail:
-                lay = {(1, 1): "fwd", (1, 0): "dX", (0, 0): "dW"}.get((args[9] if len(args) > 9 else kwargs.get("a_kc", 1),
-                                                                     args[10] if len(args) > 10 else kwargs.get("b_kc", 1)), "?")
-                return f"gemm_{'bf16' if mode else 'f32'}_{tile}_{lay}_M{M}_N{N}_K{K}", mode
-            return f"gemm_{'bf16' if mode else 'f32'}_{tile}", mode
+                return f"{fam}_{lay}_M{M}_N{N}_K{K}", mode
+            return fam, mode
         if name in ("conv_fwd", "conv_bwd") and self.detail:
             d = args[0]
             return f"{name}_Cin{d.Cin}_Cout{d.Cout}_H{d.H}_k{d.KH}{'_T' if d.transposed else ''}", None
@@ -141,15 +131,36 @@ class KernelTimer:
 
 
 def roofline_of(row):
-    """Roofline object (bench.py contract) for one summary row: MFMA-bound GEMMs / attention, HBM-bound otherwise."""
-    k = row["kernel"]
-    n = row["launches"]
-    if k.startswith("gemm_") or k.startswith("winattn"):
-        peak = MFMA_PEAK_TFLOPS[1 if row["mode"] else 0]
-        ach = row["flops"] / row["total_s"] / 1e12
-        return dict(kernel=k, bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None,
-                    launches=n, avg_launch_us=row["avg_us"], alg_flops_per_launch=row["flops"] / n,
-                    alg_bytes_per_launch=row["bytes"] / n)
-    ach = row["bytes"] / row["total_s"] / 1e9
-    return dict(kernel=k, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                traffic=None, launches=n, avg_launch_us=row["avg_us"], alg_bytes_per_launch=row["bytes"] / n)
+    """Roofline object (bench.py contract) for one summary row.  The bound is whichever of the two rooflines needs MORE
+    time for the launch's algorithmic work (flops / dense MFMA peak vs bytes / HBM peak); both are reported."""
+    k, n = row["kernel"], row["launches"]
+    peak_tf = MFMA_PEAK_TFLOPS[1 if row["mode"] else 0]
+    t_mfma = row["flops"] / (peak_tf * 1e12) if (k.startswith("gemm") or k.startswith("winattn")) else 0.0
+    t_hbm = row["bytes"] / (HBM_PEAK_GBS * 1e9)
+    tf, gb = row["flops"] / row["total_s"] / 1e12, row["bytes"] / row["total_s"] / 1e9
+    common = dict(kernel=k, launches=n, avg_launch_us=row["avg_us"], alg_flops_per_launch=row["flops"] / n,
+                  alg_bytes_per_launch=row["bytes"] / n, achieved_TFLOPs=tf, achieved_GBs=gb,
+                  frac_of_mfma_peak=tf / peak_tf, frac_of_hbm_peak=gb / HBM_PEAK_GBS, traffic=None)
+    if t_mfma > t_hbm:
+        return dict(bound="mfma", achieved=tf, peak=peak_tf, unit="TFLOP/s", frac=tf / peak_tf, **common)
+    return dict(bound="hbm", achieved=gb, peak=HBM_PEAK_GBS, unit="GB/s", frac=gb / HBM_PEAK_GBS, **common)
+
+
+def pmc_traffic(kernel_family, path):
+    """HBM bytes per launch of a kernel family from a committed PMC summary (scripts/summarize_rocprof.py --pmc output:
+    2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section), or None when no summary is present."""
+    import json
+    import os
+    if not os.path.exists(path):
+        return None
+    fams = json.load(open(path)).get("families", {})
+    pats = {"gemm_nt_kernel": ["gemm_nt_kernel"], "gemm_tn_kernel+splitk_reduce": ["gemm_tn_kernel", "splitk_reduce_kernel"]}
+    names = pats.get(kernel_family, [kernel_family.replace("_fwd", "_fwd_kernel").replace("_bwd", "_bwd_kernel")])
+    tot, launches = 0.0, 0
+    for nm in names:
+        f = fams.get(nm)
+        if not f or f.get("hbm_bytes") is None:
+            return None
+        tot += f["hbm_bytes"]
+        launches = max(launches, f["launches"])
+    return tot / launches if launches else None

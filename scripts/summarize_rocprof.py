@@ -38,6 +38,8 @@ def short(name):
 
 
 def main():
+    if sys.argv[1] == "--families":
+        return merge_families(*sys.argv[2:6])
     d, prefix = sys.argv[1], sys.argv[2]
     pmc = "--pmc" in sys.argv
     files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
@@ -73,6 +75,52 @@ def main():
         out["pmc"] = res
     json.dump(out, open(prefix + ".json", "w"), indent=1)
     print("wrote", prefix + ".json")
+
+
+def family(name):
+    """Kernel family = the __global__ function without template arguments (what bench.py's roofline object names)."""
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)(I|E)", name)
+    if m:
+        return m.group(1)
+    name = re.sub(r"\(anonymous namespace\)::", "", re.sub(r"^void ", "", name))
+    return re.split(r"[<(]", name)[0]
+
+
+def merge_families(trace_dir, fetch_dir, write_dir, prefix):
+    """Per kernel family: launches, total / average duration (kernel trace) and HBM bytes (separate FETCH_SIZE and
+    WRITE_SIZE passes; FETCH_SIZE counts 64-B units for 128-B requests on gfx950 -> x2; both are KiB)."""
+    fams = collections.defaultdict(lambda: dict(launches=0, total_ns=0, fetch_kib=None, write_kib=None, pmc_launches=0))
+    for f in glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            e = fams[family(row["Kernel_Name"])]
+            e["launches"] += 1
+            e["total_ns"] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+    for d, key in ((fetch_dir, "fetch_kib"), (write_dir, "write_kib")):
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+                    continue
+                e = fams[family(row["Kernel_Name"])]
+                e[key] = (e[key] or 0.0) + float(row["Counter_Value"])
+                if key == "fetch_kib":
+                    e["pmc_launches"] += 1
+    out = {}
+    for k, e in fams.items():
+        hb = None
+        if e["fetch_kib"] is not None and e["write_kib"] is not None and e["pmc_launches"]:
+            hb = (2.0 * e["fetch_kib"] + e["write_kib"]) * 1024.0 / e["pmc_launches"] * max(e["launches"], 1)
+        out[k] = dict(launches=e["launches"], total_ms=e["total_ns"] / 1e6,
+                      avg_us=e["total_ns"] / 1e3 / max(e["launches"], 1), hbm_bytes=hb,
+                      hbm_bytes_per_launch=(hb / e["launches"]) if (hb is not None and e["launches"]) else None)
+    json.dump({"families": out}, open(prefix + ".json", "w"), indent=1)
+    rows = sorted(out.items(), key=lambda kv: -kv[1]["total_ms"])
+    with open(prefix + ".md", "w") as fh:
+        fh.write("| kernel family | launches | total ms | avg us | HBM MB / launch (PMC) |\n|---|---|---|---|---|\n")
+        for k, e in rows[:40]:
+            hb = "" if e["hbm_bytes_per_launch"] is None else f"{e['hbm_bytes_per_launch'] / 1e6:.2f}"
+            fh.write(f"| `{k}` | {e['launches']} | {e['total_ms']:.3f} | {e['avg_us']:.1f} | {hb} |\n")
+    print("wrote", prefix + ".json", prefix + ".md")
+    return
 
 
 if __name__ == "__main__":
