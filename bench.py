@@ -24,13 +24,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 TILE_SECONDS = 1.024
 
 
-def synth_batch(batch, seed):
-    """SURVEY 8(d): chirp+noise waveforms -> data-prep STFT (256/128 rect, drop last bin) -> [B,2,128,128] tiles;
-    BinaryWM payload bits (audio_uformer_stft.py:231: randint(2,(32,32)), seed 42)."""
+def synth_waves(batch, seed):
+    """one chirp+noise waveform of 16256 samples (= exactly 128 data-prep frames) per tile."""
     from synth import chirp_wave
+    return torch.stack([chirp_wave(16384 - 128, f"bench_{seed}_{i}") for i in range(batch)])
+
+
+def synth_batch(batch, seed):
+    """Waveforms -> data-prep STFT (256/128 rect, drop last bin) -> [B,2,128,128] tiles with torch on the CPU (the
+    cpu_baseline leg; the GPU legs run the same waveforms through wm_stft256_tiles on the device);
+    BinaryWM payload bits (audio_uformer_stft.py:231: randint(2,(32,32)), seed 42)."""
+    waves = synth_waves(batch, seed)
     tiles = []
     for i in range(batch):
-        w = chirp_wave(16384 - 128, f"bench_{seed}_{i}")[None]
+        w = waves[i][None]
         st = torch.stft(w, n_fft=256, hop_length=128, win_length=256, window=torch.ones(256), return_complex=True)
         st = torch.view_as_real(st)[:, :-1]                       # [1,128,frames,2]  (audio_test.py:465-469)
         st = torch.nn.functional.pad(st, (0, 0, 0, 128 - st.shape[2]))
@@ -103,8 +110,12 @@ def main():
     attack = wm.AttackConfig.full_stack() if a.attack == "full" else None
     extract_from = "attacked" if attack is not None else "y"
     step = wm.TrainStep(net, opt, a.batch, attack=attack, extract_from=extract_from, use_graph=not a.no_graph)
-    x, msg = synth_batch(a.batch, rank)
-    x, msg = x.to(dev), msg.to(dev)
+    g = torch.Generator().manual_seed(42 + rank)
+    msg = torch.randint(0, 2, (a.batch, 1, 32, 32), generator=g).float().to(dev)
+    # waveform in: the data-prep STFT runs on the device (row A1); 16256 samples = 128 frames, the reference's padding rule
+    # then appends one all-zero tile per utterance, which is dropped here as the reference's DataLoader would batch it away
+    tiles, n_per = wm.dataprep.stft_tiles(synth_waves(a.batch, rank).to(dev))
+    x = tiles.view(a.batch, n_per, 2, 128, 128)[:, 0].contiguous()
 
     def barrier():
         if world > 1:

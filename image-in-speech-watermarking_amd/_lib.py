@@ -64,6 +64,8 @@ _SIGS = {
     "wm_conv_bwd": [C.POINTER(WmConv), c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f],
     "wm_maxpool_fwd": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_maxpool_bwd": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_stft256_tiles_per_utterance": [c_i64],
+    "wm_stft256_tiles": [c_f, c_i64, c_i32, c_f, c_fl, c_f],
     "wm_istft255_fwd": [c_f, c_f, c_i32, c_f],
     "wm_stft255_fwd": [c_f, c_f, c_i32, c_f],
     "wm_istft255_bwd": [c_f, c_f, c_i32, c_f],

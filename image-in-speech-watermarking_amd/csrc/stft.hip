@@ -145,7 +145,70 @@ __global__ __launch_bounds__(256) void analysis_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Data-prep STFT (row A1): torch.stft(n_fft=256, hop=128, win=256 rectangular, center=True, reflect) of whole
+// utterances, last bin dropped, frames zero-padded to the reference's tile count, written straight as
+// [tile][re|im][bin][frame] tiles (audio_test.py:465-488,507-519).  One workgroup = 16 frames x 128 bins of one
+// utterance: the 16 frames' 2176 + 128 samples (hop 128, so consecutive frames share half their samples) and the
+// 256-entry twiddle table live in LDS; a thread owns one bin of 8 frames, so each (plane, bin) row leaves as two
+// 16-byte stores.  Direct DFT: 8.4 MFLOP per tile, the kernel is bound by its 131 KB of output per tile.
+__global__ __launch_bounds__(256) void stft256_tiles_kernel(const float* __restrict__ wave, float* __restrict__ tiles,
+                                                            int64_t L, int nframes, int tiles_per_utt, float scale) {
+  __shared__ float xs[16 * 128 + 128];
+  __shared__ float tw[256];
+  const int tid = threadIdx.x;
+  const int groups = tiles_per_utt * 8;                       // 16-frame groups per utterance
+  const int u = blockIdx.x / groups, gq = blockIdx.x % groups, f0 = gq * 16;
+  tw[tid] = cospif(tid * (1.0f / 128.0f));
+  const float* w = wave + (int64_t)u * L;
+  for (int i = tid; i < 16 * 128 + 128; i += 256) {
+    int64_t p = (int64_t)f0 * 128 + i - 128;                  // sample index before centre padding
+    if (p < 0) p = -p;                                        // reflect (no edge repeat), pad = 128 < L
+    if (p >= L) p = 2 * (L - 1) - p;
+    xs[i] = (p >= 0 && p < L) ? w[p] : 0.f;
+  }
+  __syncthreads();
+  const int k = tid & 127, half = tid >> 7;
+  float re[8], im[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float* x = xs + (half * 8 + j) * 128;
+    float ar = 0.f, ai = 0.f;
+    int idx = 0;
+#pragma unroll 8
+    for (int n = 0; n < 256; ++n) {
+      const float v = x[n];
+      ar = fmaf(v, tw[idx], ar);                              // cos(2 pi k n / 256)
+      ai = fmaf(v, tw[(idx + 64) & 255], ai);                 // -sin(2 pi k n / 256) = cos(2 pi (kn + 64) / 256)
+      idx = (idx + k) & 255;
+    }
+    const bool live = f0 + half * 8 + j < nframes;
+    re[j] = live ? ar * scale : 0.f;
+    im[j] = live ? ai * scale : 0.f;
+  }
+  const int tile = f0 >> 7, fl = (f0 & 127) + half * 8;
+  float* o = tiles + (((int64_t)(u * tiles_per_utt + tile) * 2) * 128 + k) * 128 + fl;
+  *reinterpret_cast<float4*>(o) = make_float4(re[0], re[1], re[2], re[3]);
+  *reinterpret_cast<float4*>(o + 4) = make_float4(re[4], re[5], re[6], re[7]);
+  *reinterpret_cast<float4*>(o + 128 * 128) = make_float4(im[0], im[1], im[2], im[3]);
+  *reinterpret_cast<float4*>(o + 128 * 128 + 4) = make_float4(im[4], im[5], im[6], im[7]);
+}
+
 }  // namespace
+
+extern "C" int32_t wm_stft256_tiles_per_utterance(int64_t L) {
+  const int64_t frames = 1 + L / 128;
+  return (int32_t)(frames / 128 + 1);                         // pad = 128 - frames % 128 (audio_test.py:476-477): always >= 1 tile
+}
+
+extern "C" int wm_stft256_tiles(const float* wave, int64_t L, int32_t U, float* tiles, float scale, void* stream) {
+  if (!wave || !tiles || U <= 0 || L <= 128) return WM_EINVAL;
+  const int nframes = (int)(1 + L / 128), tpu = wm_stft256_tiles_per_utterance(L);
+  hipLaunchKernelGGL(stft256_tiles_kernel, dim3(U * tpu * 8), dim3(256), 0, static_cast<hipStream_t>(stream), wave, tiles, L,
+                     nframes, tpu, scale);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
 
 extern "C" int wm_istft255_fwd(const float* spec, float* wave, int32_t B, void* stream) {
   if (!spec || !wave || B <= 0) return WM_EINVAL;

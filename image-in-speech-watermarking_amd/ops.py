@@ -181,6 +181,17 @@ def maxpool_bwd(x, dy, dx, planes, H, W, kh, kw, accumulate=False):
           "wm_maxpool_bwd")
 
 
+def stft256_tiles(wave, scale=1.0):
+    """Data-prep STFT of U equal-length utterances [U, L] -> [U * tiles_per_utterance, 2, 128, 128] tiles."""
+    if wave.dim() != 2 or wave.dtype != torch.float32 or not wave.is_contiguous():
+        raise ValueError("stft256_tiles takes a contiguous float32 [U, L] waveform batch")
+    U, L = wave.shape
+    tpu = lib.wm_stft256_tiles_per_utterance(L)
+    tiles = torch.empty(U * tpu, 2, 128, 128, device=wave.device)
+    check(lib.wm_stft256_tiles(ptr(wave), L, U, ptr(tiles), float(scale), _stream()), "wm_stft256_tiles")
+    return tiles
+
+
 def istft_fwd(spec, wave, B):
     check(lib.wm_istft255_fwd(ptr(spec), ptr(wave), B, _stream()), "wm_istft255_fwd")
 

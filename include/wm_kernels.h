@@ -128,6 +128,13 @@ int wm_maxpool_fwd(const float* x, float* y, int32_t planes, int32_t H, int32_t 
 int wm_maxpool_bwd(const float* x, const float* dy, float* dx, int32_t planes, int32_t H, int32_t W,
                    int32_t kh, int32_t kw, int32_t accumulate, void* stream);
 
+/* ---- data-prep STFT (audio_test.py:465-488,507-519): torch.stft(n_fft=256, hop 128, rectangular window, centre /
+ * reflect) of U utterances of L samples each, bin 128 dropped, frames zero-padded to wm_stft256_tiles_per_utterance(L)
+ * tiles of 128 frames (the reference always appends at least one padded frame column), times `scale`.
+ * wave: [U, L], tiles: [U * tiles_per_utterance, 2, 128, 128] (re|im planes, [bin][frame]).                        */
+int32_t wm_stft256_tiles_per_utterance(int64_t L);
+int wm_stft256_tiles(const float* wave, int64_t L, int32_t U, float* tiles, float scale, void* stream);
+
 /* ---- in-graph STFT round trip — torch.istft / torch.stft with n_fft=255, hop 63, rectangular
  * window, center/reflect (model.py:2458,2463).  spec: [B,2,128,128] (re|im planes), wave: [B,8002] */
 int wm_istft255_fwd(const float* spec, float* wave, int32_t B, void* stream);

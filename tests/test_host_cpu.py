@@ -22,7 +22,7 @@ def wm():
 
 def test_library_exports_every_declared_symbol(wm):
     hdr = open(os.path.join(ROOT, "include", "wm_kernels.h")).read()
-    declared = set(re.findall(r"^(?:int|int64_t) (wm_[a-z0-9_]+)\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|int32_t) (wm_[a-z0-9_]+)\(", hdr, flags=re.M))
     assert declared, "header parse failed"
     for sym in declared:
         assert hasattr(wm.lib, sym), f"{sym} declared in include/wm_kernels.h but not exported by libwm_hip.so"

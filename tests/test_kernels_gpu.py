@@ -618,3 +618,32 @@ def test_elementwise_kernels_bf16_storage(wm):
     c16 = torch.empty(src.numel(), device="cuda", dtype=bf)
     ops.cast_bf16(src, c16, src.numel())
     assert torch.equal(c16, src.flatten().to(bf))
+
+
+# ------------------------------------------------------------------------ data-prep STFT (row A1) + payload tiling (A14)
+def test_dataprep_stft_tiles_match_reference_golden(wm, golden):
+    """wm_stft256_tiles against the tiles the reference's own torch.stft(256/128) + pad + split produced (G2)."""
+    from synth import chirp_wave
+    ref = torch.from_numpy(golden("g2_dataprep")["tiles"])
+    w = chirp_wave(48000, "g2_chirp")[None].cuda()
+    tiles, n = wm.dataprep.stft_tiles(w)
+    assert n == 3 and tiles.shape == (3, 2, 128, 128)
+    assert_close(tiles, ref, 1e-5, "data-prep STFT tiles")
+    # two utterances at once + audio_scale; a length whose frame count is a multiple of 128 gets one all-padding tile
+    w2 = torch.stack([chirp_wave(16256, "dp_a"), chirp_wave(16256, "dp_b")]).cuda()
+    t2, n2 = wm.dataprep.stft_tiles(w2, scale=0.5)
+    assert n2 == 2 and float(t2[1].abs().max()) == 0.0 and float(t2[3].abs().max()) == 0.0
+    st = torch.stft(w2.cpu(), n_fft=256, hop_length=128, win_length=256, window=torch.ones(256), return_complex=True)
+    want = torch.view_as_real(st)[:, :-1].permute(0, 3, 1, 2) * 0.5
+    assert_close(t2[0::2], want, 1e-5, "data-prep STFT, batch of utterances")
+
+
+def test_payload_quadrant_tiling_roundtrip(wm):
+    dp = wm.dataprep
+    img = torch.rand(3, 1, 64, 64, device="cuda")
+    q = dp.split_payload(img)
+    assert torch.equal(q[:, 1, 0], img[:, 0, :32, 32:]) and torch.equal(q[:, 2, 0], img[:, 0, 32:, :32])
+    assert torch.equal(dp.merge_payload(q), img)
+    per_tile = dp.payload_for_tiles(img, 10)                         # 10 s clip = 10 tiles
+    assert per_tile.shape == (30, 1, 32, 32) and torch.equal(per_tile[4], q[0, 0]) and torch.equal(per_tile[13], q[1, 3])
+    assert torch.allclose(dp.payload_from_tiles(per_tile, 10), img)
