@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=24, help="tiles per GPU (reference hard-codes 24, audio_uformer_stft.py:50)")
     ap.add_argument("--attack", default="none", choices=["none", "full"])
+    ap.add_argument("--clip-seconds", type=int, default=1, choices=[1, 10],
+                    help="10: config 5 (10 s clips = 10 tiles each, 64x64 grayscale payload as four quadrants; --batch must be a multiple of 10)")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,11 +113,22 @@ def main():
     extract_from = "attacked" if attack is not None else "y"
     step = wm.TrainStep(net, opt, a.batch, attack=attack, extract_from=extract_from, use_graph=not a.no_graph)
     g = torch.Generator().manual_seed(42 + rank)
-    msg = torch.randint(0, 2, (a.batch, 1, 32, 32), generator=g).float().to(dev)
-    # waveform in: the data-prep STFT runs on the device (row A1); 16256 samples = 128 frames, the reference's padding rule
-    # then appends one all-zero tile per utterance, which is dropped here as the reference's DataLoader would batch it away
-    tiles, n_per = wm.dataprep.stft_tiles(synth_waves(a.batch, rank).to(dev))
-    x = tiles.view(a.batch, n_per, 2, 128, 128)[:, 0].contiguous()
+    # waveform in: the data-prep STFT runs on the device (row A1).  A clip of 128 * k frames gets one extra all-zero tile
+    # from the reference's padding rule (audio_test.py:476-477); it carries no audio and is dropped here
+    if a.clip_seconds == 10:
+        if a.batch % 10:
+            raise SystemExit("--clip-seconds 10 needs --batch to be a multiple of 10 tiles")
+        from synth import chirp_wave
+        clips = a.batch // 10
+        waves = torch.stack([chirp_wave(10 * 16384 - 128, f"bench10_{rank}_{i}") for i in range(clips)]).to(dev)
+        tiles, n_per = wm.dataprep.stft_tiles(waves)
+        x = tiles.view(clips, n_per, 2, 128, 128)[:, :10].reshape(a.batch, 2, 128, 128).contiguous()
+        img = torch.rand(clips, 1, 64, 64, generator=g).to(dev)                  # grayscale payload in [0, 1]
+        msg = wm.dataprep.payload_for_tiles(img, 10).contiguous()
+    else:
+        msg = torch.randint(0, 2, (a.batch, 1, 32, 32), generator=g).float().to(dev)
+        tiles, n_per = wm.dataprep.stft_tiles(synth_waves(a.batch, rank).to(dev))
+        x = tiles.view(a.batch, n_per, 2, 128, 128)[:, 0].contiguous()
 
     def barrier():
         if world > 1:
@@ -140,7 +153,9 @@ def main():
         "metric": "audio-sec/s per train step (enc+attack+dec)", "value": world * a.batch * TILE_SECONDS * a.steps / dt,
         "unit": "audio-sec/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
-        "config": {"workload": ("uformerWM Uformer-STFT, 1 s 16 kHz clips, 32x32 binary image payload, "
+        "config": {"workload": (("uformerWM Uformer-STFT, 10 s 16 kHz clips (10 tiles each), 64x64 grayscale payload as 4 quadrants, "
+                                 if a.clip_seconds == 10 else
+                                 "uformerWM Uformer-STFT, 1 s 16 kHz clips, 32x32 binary image payload, ")
                                 + ("full audio_attack stack (resample+AWGN20dB+low-pass+amp0.8)" if attack else "Identity attack")
                                 + f", {a.mode}"),
                    "tiles_per_gpu": a.batch, "global_tiles": world * a.batch, "audio_sec_per_tile": TILE_SECONDS,

@@ -8,3 +8,4 @@ from . import ops, attacks, dataprep  # noqa: F401
 from .model import UformerAudio, get_arch  # noqa: F401,E402
 from .train import FusedAdamW, TrainStep, GradSync  # noqa: F401,E402
 from .attacks import AttackConfig  # noqa: F401,E402
+from .small_models import ModelA, HiddenDecoder, ConvBNRelu, Noiser, Identity, decoded_ber, mse_loss  # noqa: F401,E402

@@ -239,3 +239,26 @@ def droppath_scales(scales, rates, nslots, B, seed, step_t):
 
 def axpbyz(out, a, x, b, y, n):
     check(lib.wm_axpbyz(ptr(out), a, ptr(x), b, ptr(y), n, _stream()), "wm_axpbyz")
+
+
+# ---- small CNN models (ModelA, HiDDeN decoder) ------------------------------------------------------------------
+def batchnorm2d_fwd(x, gamma, beta, rmean, rvar, y, save_mean, save_invstd, eps, momentum, training, act="none", slope=0.0):
+    B, Cc, H, W = x.shape
+    check(lib.wm_batchnorm2d_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ptr(y), ptr(save_mean),
+                                 ptr(save_invstd), B, Cc, H * W, eps, momentum, int(training), ACT[act], slope, _stream()),
+          "wm_batchnorm2d_fwd")
+
+
+def batchnorm2d_bwd(dy, x, y, gamma, save_mean, save_invstd, dx, dgamma, dbeta, sums, training, act="none", slope=0.0):
+    B, Cc, H, W = x.shape
+    check(lib.wm_batchnorm2d_bwd(ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(dx), ptr(dgamma),
+                                 ptr(dbeta), ptr(sums), B, Cc, H * W, int(training), ACT[act], slope, _stream()),
+          "wm_batchnorm2d_bwd")
+
+
+def dropout(x, y, p, seed, offset):
+    check(lib.wm_dropout(ptr(x), ptr(y), x.numel(), p, seed, offset, _stream()), "wm_dropout")
+
+
+def mse_fwd_bwd(a, b, loss, da=None, db=None, gscale=1.0):
+    check(lib.wm_mse_fwd_bwd(ptr(a), ptr(b), a.numel(), ptr(loss), ptr(da), ptr(db), gscale, _stream()), "wm_mse_fwd_bwd")

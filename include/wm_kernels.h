@@ -176,6 +176,25 @@ int wm_axpbyz(float* out, float a, const float* x, float b, const float* y /* or
 int wm_msg_expand_fwd(const float* feat, float* dst, int32_t B, void* stream);
 int wm_msg_expand_bwd(const float* dcat, float* dfeat, int32_t B, void* stream);
 
+/* ---- layers of the small CNN models: ModelA (model.py:3000-3066, train_modelA.py:423-445) and the HiDDeN decoder
+ * (hidden/model/decoder.py:6-40, conv_bn_relu.py:3-18); their convolutions / pools use wm_conv_* / wm_maxpool_*.
+ * BatchNorm2d on NCHW fp32 with a fused activation (act: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 sigmoid).
+ * training != 0: batch statistics (biased variance for the normalisation; running_mean/var, if given, updated with
+ * `momentum` and the unbiased variance, as nn.BatchNorm2d does); training == 0: the running statistics.
+ * save_mean / save_invstd [C] are outputs kept for the backward; bwd ACCUMULATES dgamma / dbeta, `sums` is [2C] scratch. */
+int wm_batchnorm2d_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       float* y, float* save_mean, float* save_invstd, int32_t B, int32_t C, int32_t HW, float eps,
+                       float momentum, int32_t training, int32_t act, float slope, void* stream);
+int wm_batchnorm2d_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
+                       const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* sums, int32_t B, int32_t C,
+                       int32_t HW, int32_t training, int32_t act, float slope, void* stream);
+/* y = x * mask / (1 - p), mask = Philox(seed, offset, index) < 1 - p (nn.Dropout); the backward is the same call on dy  */
+int wm_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+/* *loss += mean((a-b)^2);  da = gscale * 2 (a-b) / n, db = -da (each NULL or output) — nn.MSELoss terms of
+ * train_modelA.py:435-445 and hidden's decoder loss                                                               */
+int wm_mse_fwd_bwd(const float* a, const float* b, int64_t n, float* loss, float* da, float* db, float gscale,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif
