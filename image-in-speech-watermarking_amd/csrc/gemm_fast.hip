@@ -17,6 +17,9 @@
 namespace {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+#ifndef NT_NBUF
+#define NT_NBUF 1
+#endif
 
 // MFMA 32x32x16 operand out of an as-it-lies [k][columns] LDS image (lane l: column l&31, k = 8*(l>>5) + j)
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int col0, int kstep, int lane) {
@@ -181,9 +184,10 @@ template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int 
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemm g, const bool vec_ok, const int tiles_n, const int tiles_m) {
   constexpr int BK = 64, BM = WM * TM * 32, BN = WN * TN * 32, LDA = BK + 8;
   constexpr int LDB = B_TR ? BN + 32 : BK + 8, BSZ = B_TR ? BK * LDB : BN * LDB;
+  constexpr int NBUF = NT_NBUF;                              // LDS operand buffers (1: more workgroups per CU, one more barrier per k tile)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __bf16* As = reinterpret_cast<__bf16*>(smem_raw);          // [2][BM][LDA]
-  __bf16* Bs = As + 2 * BM * LDA;                            // [2][BSZ]
+  __bf16* Bs = As + NBUF * BM * LDA;                         // [NBUF][BSZ]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
   int bx, by, bz;
@@ -253,113 +257,124 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemm g, const bool
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    const int nb = NBUF == 2 ? buf ^ 1 : 0;
+    if (NBUF == 1) __syncthreads();                           // every wave is done reading the single buffer
     if (nx < nfull) {
-      sa.store_full(As + (buf ^ 1) * BM * LDA);
-      if constexpr (B_TR) sbt.store_full(Bs + (buf ^ 1) * BSZ, false); else sbk.store_full(Bs + (buf ^ 1) * BSZ);
+      sa.store_full(As + nb * BM * LDA);
+      if constexpr (B_TR) sbt.store_full(Bs + nb * BSZ, false); else sbk.store_full(Bs + nb * BSZ);
     } else if (nx < ntiles) {
-      sa.store_tail(As + (buf ^ 1) * BM * LDA, nx * BK, K);
-      if constexpr (B_TR) sbt.store_tail(Bs + (buf ^ 1) * BSZ, false, nx * BK, K); else sbk.store_tail(Bs + (buf ^ 1) * BSZ, nx * BK, K);
+      sa.store_tail(As + nb * BM * LDA, nx * BK, K);
+      if constexpr (B_TR) sbt.store_tail(Bs + nb * BSZ, false, nx * BK, K); else sbk.store_tail(Bs + nb * BSZ, nx * BK, K);
     }
     __syncthreads();
-    buf ^= 1;
+    buf = nb;
   }
 
-  // epilogue: accumulators -> LDS (fp32 tile) -> coalesced 16-byte rows
-  constexpr int LDC = BN + 4;
+  // epilogue: accumulators -> LDS (fp32) -> coalesced 16-byte rows, one wave-row (TM * 32 rows) of the tile per pass so that
+  // the staging image is 1 / WM of the tile (the full fp32 tile was the largest LDS user and capped the workgroups per CU)
+  constexpr int LDC = BN + 4, PR = TM * 32;                  // rows per pass
   float* Cs = reinterpret_cast<float*>(smem_raw);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        Cs[((wm * TM + i) * 32 + mma32_row(e, h)) * LDC + (wn * TN + j) * 32 + r] = acc[i][j][e];
-  __syncthreads();
   constexpr int TPRW = BN / 4, RPP = 256 / TPRW;
   const int c4 = tid % TPRW, n = n0 + 4 * c4;
   const bool full = vec_ok && n + 3 < g.N;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (full && g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + n);
-  if (full) {
-    // All epilogue operands of a group of rows (DropPath scale, gelu' factor, residual) are requested BEFORE the first
-    // one is used: written as one loop the compiler waited for every load in turn, ~3 round trips per row and 16 rows
-    // per thread, which dominated the short-K launches.
-    constexpr int NR = BM / RPP, G = NR < 8 ? NR : 8;
-    const int r0 = tid / TPRW;
-    const bool sc_uniform = g.rowscale && (g.rows_per_scale % BM) == 0;       // one sample per row tile
-    const float sc_tile = sc_uniform ? g.rowscale[m0 / g.rows_per_scale] : 1.f;
+  const bool sc_uniform = g.rowscale && (g.rows_per_scale % BM) == 0;       // one sample per row tile
+  const float sc_tile = sc_uniform ? g.rowscale[m0 / g.rows_per_scale] : 1.f;
+#pragma unroll 1
+  for (int pass = 0; pass < WM; ++pass) {
+    __syncthreads();
+    if (wm == pass) {
 #pragma unroll
-    for (int g0 = 0; g0 < NR; g0 += G) {
-      uint4 ga[G];
-      float4 re[G];
-      float sc[G];
-      int64_t mrow[G];
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int q = 0; q < G; ++q) {
-        mrow[q] = min(m0 + r0 + (g0 + q) * RPP, g.M - 1);
-        sc[q] = sc_tile;
-      }
-      // one straight-line loop per operand (a per-row if / else makes the compiler drain the loads row by row)
-      if (g.rowscale && !sc_uniform) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int q = 0; q < G; ++q) sc[q] = g.rowscale[mrow[q] / g.rows_per_scale];
-      }
-      if (g.gaux && g.gaux_bf16) {
+          for (int e = 0; e < 16; ++e)
+            Cs[(i * 32 + mma32_row(e, h)) * LDC + (wn * TN + j) * 32 + r] = acc[i][j][e];
+    }
+    __syncthreads();
+    const int mp = m0 + pass * PR;                            // first row of this pass
+    if (full) {
+      // All epilogue operands of a group of rows (DropPath scale, gelu' factor, residual) are requested BEFORE the first
+      // one is used: written as one loop the compiler waited for every load in turn, ~3 round trips per row, which
+      // dominated the short-K launches.
+      constexpr int NR = PR / RPP, G = NR < 8 ? NR : 8;
+      static_assert(NR >= 1 && NR % G == 0, "rows per thread");
+      const int r0 = tid / TPRW;
+#pragma unroll
+      for (int g0 = 0; g0 < NR; g0 += G) {
+        uint4 ga[G];
+        float4 re[G];
+        float sc[G];
+        int64_t mrow[G];
 #pragma unroll
         for (int q = 0; q < G; ++q) {
-          const uint2 t = *reinterpret_cast<const uint2*>(static_cast<const __bf16*>(g.gaux) + mrow[q] * g.ldg + n);
-          ga[q] = make_uint4(t.x, t.y, 0u, 0u);
+          mrow[q] = min(mp + r0 + (g0 + q) * RPP, g.M - 1);
+          sc[q] = sc_tile;
         }
-      } else if (g.gaux) {
+        // one straight-line loop per operand (a per-row if / else makes the compiler drain the loads row by row)
+        if (g.rowscale && !sc_uniform) {
 #pragma unroll
-        for (int q = 0; q < G; ++q) ga[q] = *reinterpret_cast<const uint4*>(static_cast<const float*>(g.gaux) + mrow[q] * g.ldg + n);
-      }
-      if (g.res) {
+          for (int q = 0; q < G; ++q) sc[q] = g.rowscale[mrow[q] / g.rows_per_scale];
+        }
+        if (g.gaux && g.gaux_bf16) {
 #pragma unroll
-        for (int q = 0; q < G; ++q) re[q] = *reinterpret_cast<const float4*>(g.res + mrow[q] * g.ldr + n);
-      }
-#pragma unroll
-      for (int q = 0; q < G; ++q) {
-        const int rr = r0 + (g0 + q) * RPP, m = m0 + rr;
-        if (m < g.M) {
-          float4 v = *reinterpret_cast<const float4*>(Cs + rr * LDC + 4 * c4);
-          v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-          if (g.rowscale) { v.x *= sc[q]; v.y *= sc[q]; v.z *= sc[q]; v.w *= sc[q]; }
-          if (g.gaux) {
-            float4 a;
-            if (g.gaux_bf16) a = make_float4(bf_lo(ga[q].x), bf_hi(ga[q].x), bf_lo(ga[q].y), bf_hi(ga[q].y));
-            else a = make_float4(__uint_as_float(ga[q].x), __uint_as_float(ga[q].y), __uint_as_float(ga[q].z), __uint_as_float(ga[q].w));
-            if (g.gaux_raw) { v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w; }
-            else { v.x *= gelu_grad_f(a.x); v.y *= gelu_grad_f(a.y); v.z *= gelu_grad_f(a.z); v.w *= gelu_grad_f(a.w); }
+          for (int q = 0; q < G; ++q) {
+            const uint2 t = *reinterpret_cast<const uint2*>(static_cast<const __bf16*>(g.gaux) + mrow[q] * g.ldg + n);
+            ga[q] = make_uint4(t.x, t.y, 0u, 0u);
           }
-          if (g.res) { v.x += re[q].x; v.y += re[q].y; v.z += re[q].z; v.w += re[q].w; }
-          if (g.c_bf16) IO<__bf16>::st4(static_cast<__bf16*>(g.C) + (int64_t)m * g.ldc + n, v);
-          else IO<float>::st4(static_cast<float*>(g.C) + (int64_t)m * g.ldc + n, v);
+        } else if (g.gaux) {
+#pragma unroll
+          for (int q = 0; q < G; ++q) ga[q] = *reinterpret_cast<const uint4*>(static_cast<const float*>(g.gaux) + mrow[q] * g.ldg + n);
+        }
+        if (g.res) {
+#pragma unroll
+          for (int q = 0; q < G; ++q) re[q] = *reinterpret_cast<const float4*>(g.res + mrow[q] * g.ldr + n);
+        }
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+          const int rr = r0 + (g0 + q) * RPP, m = mp + rr;
+          if (m < g.M) {
+            float4 v = *reinterpret_cast<const float4*>(Cs + rr * LDC + 4 * c4);
+            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+            if (g.rowscale) { v.x *= sc[q]; v.y *= sc[q]; v.z *= sc[q]; v.w *= sc[q]; }
+            if (g.gaux) {
+              float4 a;
+              if (g.gaux_bf16) a = make_float4(bf_lo(ga[q].x), bf_hi(ga[q].x), bf_lo(ga[q].y), bf_hi(ga[q].y));
+              else a = make_float4(__uint_as_float(ga[q].x), __uint_as_float(ga[q].y), __uint_as_float(ga[q].z), __uint_as_float(ga[q].w));
+              if (g.gaux_raw) { v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w; }
+              else { v.x *= gelu_grad_f(a.x); v.y *= gelu_grad_f(a.y); v.z *= gelu_grad_f(a.z); v.w *= gelu_grad_f(a.w); }
+            }
+            if (g.res) { v.x += re[q].x; v.y += re[q].y; v.z += re[q].z; v.w += re[q].w; }
+            if (g.c_bf16) IO<__bf16>::st4(static_cast<__bf16*>(g.C) + (int64_t)m * g.ldc + n, v);
+            else IO<float>::st4(static_cast<float*>(g.C) + (int64_t)m * g.ldc + n, v);
+          }
         }
       }
-    }
-    return;
-  }
-  for (int rr = tid / TPRW; rr < BM; rr += RPP) {            // column-edge tiles / unaligned operands: scalar path
-    const int m = m0 + rr;
-    if (m >= g.M) break;
-    const float4 v = *reinterpret_cast<const float4*>(Cs + rr * LDC + 4 * c4);
-    const float e4[4] = {v.x, v.y, v.z, v.w};
+    } else {
+      for (int rr = tid / TPRW; rr < PR; rr += RPP) {         // column-edge tiles / unaligned operands: scalar path
+        const int m = mp + rr;
+        if (m >= g.M) break;
+        const float4 v = *reinterpret_cast<const float4*>(Cs + rr * LDC + 4 * c4);
+        const float e4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int nn = n + q;
-      if (nn >= g.N) continue;
-      float val = e4[q];
-      if (g.bias) val += g.bias[nn];
-      if (g.rowscale) val *= g.rowscale[m / g.rows_per_scale];
-      if (g.gaux) {
-        const float av = g.gaux_bf16 ? (float)static_cast<const __bf16*>(g.gaux)[(int64_t)m * g.ldg + nn]
-                                     : static_cast<const float*>(g.gaux)[(int64_t)m * g.ldg + nn];
-        val *= g.gaux_raw ? av : gelu_grad_f(av);
+        for (int q = 0; q < 4; ++q) {
+          const int nn = n + q;
+          if (nn >= g.N) continue;
+          float val = e4[q];
+          if (g.bias) val += g.bias[nn];
+          if (g.rowscale) val *= g.rowscale[m / g.rows_per_scale];
+          if (g.gaux) {
+            const float av = g.gaux_bf16 ? (float)static_cast<const __bf16*>(g.gaux)[(int64_t)m * g.ldg + nn]
+                                         : static_cast<const float*>(g.gaux)[(int64_t)m * g.ldg + nn];
+            val *= g.gaux_raw ? av : gelu_grad_f(av);
+          }
+          if (g.res) val += g.res[(int64_t)m * g.ldr + nn];
+          if (g.c_bf16) static_cast<__bf16*>(g.C)[(int64_t)m * g.ldc + nn] = (__bf16)val;
+          else static_cast<float*>(g.C)[(int64_t)m * g.ldc + nn] = val;
+        }
       }
-      if (g.res) val += g.res[(int64_t)m * g.ldr + nn];
-      if (g.c_bf16) static_cast<__bf16*>(g.C)[(int64_t)m * g.ldc + nn] = (__bf16)val;
-      else static_cast<float*>(g.C)[(int64_t)m * g.ldc + nn] = val;
     }
   }
 }
@@ -494,7 +509,7 @@ template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int 
 int launch_nt(const WmGemm& g, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 64;
   constexpr size_t bsz = B_TR ? BK * (BN + 32) : BN * (BK + 8);
-  constexpr size_t stage = 2 * 2 * (BM * (BK + 8) + bsz), ctile = sizeof(float) * BM * (BN + 4);
+  constexpr size_t stage = NT_NBUF * 2 * (BM * (BK + 8) + bsz), ctile = sizeof(float) * TM * 32 * (BN + 4);
   constexpr size_t smem = stage > ctile ? stage : ctile;
   static bool attr = false;
   if (!attr) {
