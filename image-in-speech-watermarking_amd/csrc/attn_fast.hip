@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void attn_bwd_fast_kernel(const __bf16* __restr
 #pragma unroll
       for (int e = 0; e < 16; ++e) accb[a][b2][e] = 0.f;
 
-  int nrow[4], row[4], b, wy, wx, nb, nwy, nwx;
+  int nrow[4], row[4], wy, wx, nb, nwy, nwx;
   u32x4 pq[4], pk[4], pv[4], pd[4], po[4];
   float plse;
   const int w0 = chunk < nwin ? chunk : nwin - 1;             // (a block without work still loads valid addresses)
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64) void attn_bwd_fast_kernel(const __bf16* __restr
   tile_load(po, out, g.C, col, nrow);
   plse = lse_g[(int64_t)g.token_row(nb, nwy, nwx, lane) * g.heads + head];
   for (int w = chunk; w < nwin; w += nchunk) {
-    b = nb, wy = nwy, wx = nwx;
+    wy = nwy, wx = nwx;
 #pragma unroll
     for (int it = 0; it < 4; ++it) row[it] = nrow[it];
     __syncthreads();
