@@ -8,7 +8,11 @@ ops = wm.ops
 bf = torch.bfloat16
 dev = "cuda"
 iters = int(os.environ.get("ITERS", "24"))
-shapes = [("fwd", 24576, 256, 1024, {}), ("fwd", 24576, 256, 1024, {"res": 1}), ("fwd", 24576, 1024, 256, {}),
+if os.environ.get("BIG"):
+    shapes = [("fwd", 98304, 1024, 256, {}), ("fwd", 98304, 256, 1024, {"res": 1}), ("dX", 98304, 1024, 256, {"gaux": 1, "a32": 1}),
+              ("dX", 24576, 2048, 512, {"gaux": 1, "a32": 1})]
+else:
+  shapes = [("fwd", 24576, 256, 1024, {}), ("fwd", 24576, 256, 1024, {"res": 1}), ("fwd", 24576, 1024, 256, {}),
           ("fwd", 98304, 128, 128, {}), ("fwd", 393216, 96, 32, {}),
           ("dX", 24576, 1024, 256, {}), ("dX", 24576, 1024, 256, {"gaux": 1}), ("dX", 24576, 256, 1024, {"a32": 1}),
           ("dW", 512, 2048, 6144, {}), ("dW", 512, 128, 24576, {}), ("dW", 256, 1024, 24576, {"a32": 1})]
