@@ -76,6 +76,7 @@ _SIGS = {
     "wm_adamw": [c_f, c_f, c_f, c_f, c_i64, c_f, c_fl, c_fl, c_fl, c_fl, c_f, c_f, c_f],
     "wm_step_inc": [c_f, c_f],
     "wm_droppath_scales": [c_f, c_f, c_i32, c_i32, c_u64, c_f, c_f],
+    "wm_zero": [c_f, c_i64, c_f],
     "wm_axpbyz": [c_f, c_fl, c_f, c_fl, c_f, c_i64, c_f],
     "wm_batchnorm2d_fwd": [c_f] * 8 + [c_i32, c_i32, c_i32, c_fl, c_fl, c_i32, c_i32, c_fl, c_f],
     "wm_batchnorm2d_bwd": [c_f] * 10 + [c_i32, c_i32, c_i32, c_i32, c_i32, c_fl, c_f],

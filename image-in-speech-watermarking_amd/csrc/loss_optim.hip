@@ -86,6 +86,12 @@ __global__ void step_inc_kernel(int64_t* step) { *step += 1; }
 __global__ void zero_small_kernel(float* p, int n) {
   if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
 }
+// clears the gradient arena / accumulation targets (a kernel node, for the same reason as zero_small_kernel)
+__global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, int64_t n16, float* __restrict__ tail, int ntail) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) p[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
 
 __global__ void droppath_kernel(float* __restrict__ scales, const float* __restrict__ rates, int nslots, int B,
                                 uint64_t seed, const int64_t* __restrict__ step) {
@@ -126,6 +132,17 @@ extern "C" int wm_loss_fwd_bwd(const float* stft_new, const float* x, const floa
                      scratch + 2, (float*)nullptr);
   hipLaunchKernelGGL(loss_grad_kernel, dim3(grid_for(n1)), dim3(256), 0, st, stft_new, x, noise, wm_pred, wm, msg,
                      scratch, losses, d_stft_new, d_noise, d_wm_pred, d_wm, B, n1, n2);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int wm_zero(float* p, int64_t n, void* stream) {
+  if (!p || n <= 0 || (reinterpret_cast<uintptr_t>(p) & 15)) return WM_EINVAL;
+  const int64_t n16 = n / 4;
+  int64_t blocks = (n16 + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks);
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<uint4*>(p), n16, p + n16 * 4, (int)(n - n16 * 4));
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

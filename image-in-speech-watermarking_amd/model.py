@@ -168,7 +168,8 @@ def _E(dev, *shape):
 
 
 def _Z(dev, *shape):
-    return torch.zeros(shape, device=dev, dtype=torch.float32)
+    t = torch.empty(shape, device=dev, dtype=torch.float32)
+    return ops.zero_(t) if t.is_cuda else t.zero_()
 
 
 class UformerAudio(nn.Module):

@@ -262,3 +262,9 @@ def dropout(x, y, p, seed, offset):
 
 def mse_fwd_bwd(a, b, loss, da=None, db=None, gscale=1.0):
     check(lib.wm_mse_fwd_bwd(ptr(a), ptr(b), a.numel(), ptr(loss), ptr(da), ptr(db), gscale, _stream()), "wm_mse_fwd_bwd")
+
+
+def zero_(t):
+    """t[...] = 0 with a libwm_hip kernel (a kernel node in captured steps; no ATen fill on the hot path)."""
+    check(lib.wm_zero(ptr(t), t.numel(), _stream()), "wm_zero")
+    return t

@@ -115,7 +115,7 @@ class TrainStep:
     # -- the launch sequence (no host syncs, no python-side data dependence) ------------------------
     def _launch(self):
         net, B = self.net, self.B
-        net._flat_grad.zero_()
+        ops.zero_(net._flat_grad)
         ops.step_inc(net._step_t)                               # advances the DropPath / AWGN Philox streams
         outs, S = net._forward_impl(self.x, self.msg, train=net.training, keep_scales=None, attack=self.attack,
                                     extract_from=self.extract_from)

@@ -169,6 +169,8 @@ int wm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const floa
 int wm_step_inc(int64_t* step, void* stream);
 int wm_droppath_scales(float* scales, const float* rates, int32_t nslots, int32_t B, uint64_t seed,
                        const int64_t* step, void* stream);
+/* p[0..n) = 0 (16-byte aligned p): per-step clear of the gradient arena and of accumulation targets               */
+int wm_zero(float* p, int64_t n, void* stream);
 int wm_axpbyz(float* out, float a, const float* x, float b, const float* y /* or NULL */, int64_t n,
               void* stream);                                     /* out = a*x + b*y */
 /* payload feature [B,4,64] tiled (1,16,8) into channels [0,512) of the bottleneck concat [B,64,1024]
