@@ -179,8 +179,53 @@ __device__ __forceinline__ bool tile_of_block(int tiles_n, int tiles_m, int kspl
   return by < tiles_m;
 }
 
+// Interior epilogue rows (whole pass inside M, 16-byte aligned operands) for the three operand combinations that carry
+// almost every launch of the train step (EPI template parameter of the kernel).  A short-K launch spends as long here as
+// in its k loop, so the per-row work is: one LDS read, the packed arithmetic, one store, pointer bumps - no bounds
+// checks, no 64-bit multiplies, no branches.
+//   EPI 0: C(bf16) = acc + bias                              (qkv / fc1 forward, plain dX)
+//   EPI 1: C(fp32) = (acc + bias) * sc + res                 (proj / fc2 forward with DropPath scale and residual)
+//   EPI 2: C(bf16) = acc * sc * gaux(bf16 factor)            (fc2 dX times the stored gelu')
+template <int EPI, int NR, int RPP, int LDC>
+__device__ __forceinline__ void epi_interior(const float* cs, const WmGemm& g, int64_t row0, int n, float4 bias4, float sc) {
+  const int64_t cstep = (int64_t)RPP * g.ldc;
+  uint2 ga[NR];
+  float4 re[NR];
+  if constexpr (EPI == 2) {
+    const __bf16* gp = static_cast<const __bf16*>(g.gaux) + row0 * g.ldg + n;
+    const int64_t gstep = (int64_t)RPP * g.ldg;
+#pragma unroll
+    for (int q = 0; q < NR; ++q, gp += gstep) ga[q] = *reinterpret_cast<const uint2*>(gp);
+  }
+  if constexpr (EPI == 1) {
+    const float* rp = g.res + row0 * g.ldr + n;
+    const int64_t rstep = (int64_t)RPP * g.ldr;
+#pragma unroll
+    for (int q = 0; q < NR; ++q, rp += rstep) re[q] = *reinterpret_cast<const float4*>(rp);
+  }
+  if constexpr (EPI == 1) {
+    float* cf = static_cast<float*>(g.C) + row0 * g.ldc + n;
+#pragma unroll
+    for (int q = 0; q < NR; ++q, cf += cstep) {
+      float4 v = *reinterpret_cast<const float4*>(cs + q * RPP * LDC);
+      v.x = (v.x + bias4.x) * sc + re[q].x; v.y = (v.y + bias4.y) * sc + re[q].y;
+      v.z = (v.z + bias4.z) * sc + re[q].z; v.w = (v.w + bias4.w) * sc + re[q].w;
+      *reinterpret_cast<float4*>(cf) = v;
+    }
+  } else {
+    __bf16* ch = static_cast<__bf16*>(g.C) + row0 * g.ldc + n;
+#pragma unroll
+    for (int q = 0; q < NR; ++q, ch += cstep) {
+      float4 v = *reinterpret_cast<const float4*>(cs + q * RPP * LDC);
+      if constexpr (EPI == 0) { v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w; }
+      else { v.x *= sc * bf_lo(ga[q].x); v.y *= sc * bf_hi(ga[q].x); v.z *= sc * bf_lo(ga[q].y); v.w *= sc * bf_hi(ga[q].y); }
+      *reinterpret_cast<uint2*>(ch) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
-template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN>
+template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemm g, const bool vec_ok, const int tiles_n, const int tiles_m) {
   constexpr int BK = 64, BM = WM * TM * 32, BN = WN * TN * 32, LDA = BK + 8;
   constexpr int LDB = B_TR ? BN + 32 : BK + 8, BSZ = B_TR ? BK * LDB : BN * LDB;
@@ -295,6 +340,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemm g, const bool
     }
     __syncthreads();
     const int mp = m0 + pass * PR;                            // first row of this pass
+    if constexpr (EPI != 3) {
+      if (full && mp + PR <= g.M) {                           // (the host picked EPI from the operands that are present)
+        epi_interior<EPI, PR / RPP, RPP, LDC>(Cs + (tid / TPRW) * LDC + 4 * c4, g, mp + tid / TPRW, n, bias4, g.rowscale ? sc_tile : 1.f);
+        continue;
+      }
+    }
     if (full) {
       // All epilogue operands of a group of rows (DropPath scale, gelu' factor, residual) are requested BEFORE the first
       // one is used: written as one loop the compiler waited for every load in turn, ~3 round trips per row, which
@@ -505,8 +556,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int 
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN>
-int launch_nt(const WmGemm& g, hipStream_t st) {
+template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int EPI>
+int launch_nt_epi(const WmGemm& g, bool vec_ok, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 64;
   constexpr size_t bsz = B_TR ? BK * (BN + 32) : BN * (BK + 8);
   constexpr size_t stage = NT_NBUF * 2 * (BM * (BK + 8) + bsz), ctile = sizeof(float) * TM * 32 * (BN + 4);
@@ -514,17 +565,31 @@ int launch_nt(const WmGemm& g, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     if (smem > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, EPI>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-  const bool vec_ok = al16(g.C) && !(g.ldc & 7) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && !(g.ldr & 3))) &&
-                      (!g.gaux || (al16(g.gaux) && !(g.ldg & 7)));
-  hipLaunchKernelGGL((gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN>), dim3(8 * ((tiles_m + 7) / 8) * tiles_n), dim3(256),
+  hipLaunchKernelGGL((gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, EPI>), dim3(8 * ((tiles_m + 7) / 8) * tiles_n), dim3(256),
                      smem, st, g, vec_ok, tiles_n, tiles_m);
   WM_CHECK_LAUNCH();
   return WM_OK;
+}
+
+// picks the epilogue specialisation from the operands that are present (3 = general code)
+template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN>
+int launch_nt(const WmGemm& g, hipStream_t st) {
+  constexpr int BM = WM * TM * 32;
+  const bool vec_ok = al16(g.C) && !(g.ldc & 7) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && !(g.ldr & 3))) &&
+                      (!g.gaux || (al16(g.gaux) && !(g.ldg & 7)));
+  const bool sc_ok = !g.rowscale || (g.rows_per_scale % BM) == 0;
+  if (vec_ok && sc_ok) {
+    if (g.c_bf16 && !g.rowscale && !g.gaux && !g.res) return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 0>(g, vec_ok, st);
+    if (!g.c_bf16 && g.res && !g.gaux) return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 1>(g, vec_ok, st);
+    if (g.c_bf16 && g.gaux && g.gaux_raw && g.gaux_bf16 && !g.res && !g.bias)
+      return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 2>(g, vec_ok, st);
+  }
+  return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 3>(g, vec_ok, st);
 }
 
 template <typename AT, typename BT, bool B_TR, bool A_GELU>
