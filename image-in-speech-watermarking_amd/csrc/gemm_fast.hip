@@ -183,7 +183,7 @@ __device__ __forceinline__ bool tile_of_block(int tiles_n, int tiles_m, int kspl
 // almost every launch of the train step (EPI template parameter of the kernel).  A short-K launch spends as long here as
 // in its k loop, so the per-row work is: one LDS read, the packed arithmetic, one store, pointer bumps - no bounds
 // checks, no 64-bit multiplies, no branches.
-//   EPI 0: C(bf16) = acc + bias                              (qkv / fc1 forward, plain dX)
+//   EPI 0: C(bf16) = (acc + bias) * sc                       (qkv / fc1 forward, plain dX, proj dX with DropPath scale)
 //   EPI 1: C(fp32) = (acc + bias) * sc + res                 (proj / fc2 forward with DropPath scale and residual)
 //   EPI 2: C(bf16) = acc * sc * gaux(bf16 factor)            (fc2 dX times the stored gelu')
 template <int EPI, int NR, int RPP, int LDC>
@@ -217,7 +217,7 @@ __device__ __forceinline__ void epi_interior(const float* cs, const WmGemm& g, i
 #pragma unroll
     for (int q = 0; q < NR; ++q, ch += cstep) {
       float4 v = *reinterpret_cast<const float4*>(cs + q * RPP * LDC);
-      if constexpr (EPI == 0) { v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w; }
+      if constexpr (EPI == 0) { v.x = (v.x + bias4.x) * sc; v.y = (v.y + bias4.y) * sc; v.z = (v.z + bias4.z) * sc; v.w = (v.w + bias4.w) * sc; }
       else { v.x *= sc * bf_lo(ga[q].x); v.y *= sc * bf_hi(ga[q].x); v.z *= sc * bf_lo(ga[q].y); v.w *= sc * bf_hi(ga[q].y); }
       *reinterpret_cast<uint2*>(ch) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
     }
@@ -584,7 +584,7 @@ int launch_nt(const WmGemm& g, hipStream_t st) {
                       (!g.gaux || (al16(g.gaux) && !(g.ldg & 7)));
   const bool sc_ok = !g.rowscale || (g.rows_per_scale % BM) == 0;
   if (vec_ok && sc_ok) {
-    if (g.c_bf16 && !g.rowscale && !g.gaux && !g.res) return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 0>(g, vec_ok, st);
+    if (g.c_bf16 && !g.gaux && !g.res) return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 0>(g, vec_ok, st);
     if (!g.c_bf16 && g.res && !g.gaux) return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 1>(g, vec_ok, st);
     if (g.c_bf16 && g.gaux && g.gaux_raw && g.gaux_bf16 && !g.res && !g.bias)
       return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 2>(g, vec_ok, st);
