@@ -516,30 +516,45 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int 
   const int how = part ? 0 : (ksplit == 1 ? 1 : 2);
   float* const dst = part ? part + (int64_t)bz * g.M * g.N : C;
   const int64_t ldd = part ? g.N : g.ldc;
+  if (how == 0 && m0 + BM <= g.M && n0 + BN <= g.N) {
+    // interior tile of a split-K slice (the common case): one running pointer per 32 x 32 accumulator, no bounds checks
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + r;
-      float old[16];
-      if (how == 1) {                                         // all 16 reads in flight before the first add
+      for (int j = 0; j < TN; ++j) {
+        float* d = dst + (int64_t)(m0 + (wm * TM + i) * 32 + 4 * h) * ldd + n0 + (wn * TN + j) * 32 + r;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int m = min(m0 + (wm * TM + i) * 32 + mma32_row(e, h), g.M - 1);
-          old[e] = dst[m * ldd + min(n, g.N - 1)];
+          *d = acc[i][j][e];
+          d += ((e & 3) == 3) ? 5 * ldd : ldd;               // rows (e & 3) + 8 (e >> 2) + 4 h
         }
       }
+  } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + (wm * TM + i) * 32 + mma32_row(e, h);
-        if (m < g.M && n < g.N) {
-          float* d = dst + m * ldd + n;
-          if (how == 0) *d = acc[i][j][e];
-          else if (how == 1) *d = old[e] + acc[i][j][e];
-          else atomicAdd(d, acc[i][j][e]);
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + r;
+        float old[16];
+        if (how == 1) {                                       // all 16 reads in flight before the first add
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = min(m0 + (wm * TM + i) * 32 + mma32_row(e, h), g.M - 1);
+            old[e] = dst[m * ldd + min(n, g.N - 1)];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + (wm * TM + i) * 32 + mma32_row(e, h);
+          if (m < g.M && n < g.N) {
+            float* d = dst + m * ldd + n;
+            if (how == 0) *d = acc[i][j][e];
+            else if (how == 1) *d = old[e] + acc[i][j][e];
+            else atomicAdd(d, acc[i][j][e]);
+          }
         }
       }
-    }
+  }
   if (g.b_ones) {                                              // fold the thread groups through LDS: one atomic per column
     __syncthreads();
     float* red = reinterpret_cast<float*>(&As[0][0]);
