@@ -20,6 +20,12 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 #ifndef NT_NBUF
 #define NT_NBUF 1
 #endif
+#ifndef TN_NBUF
+#define TN_NBUF 1
+#endif
+#ifndef TN_TARGET
+#define TN_TARGET 768
+#endif
 
 // MFMA 32x32x16 operand out of an as-it-lies [k][columns] LDS image (lane l: column l&31, k = 8*(l>>5) + j)
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int col0, int kstep, int lane) {
@@ -437,8 +443,9 @@ template <typename AT, typename BT, bool B_GELU, int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int klen, const int tiles_n, const int tiles_m,
                                                       const int ksplit, float* __restrict__ part) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 32, LDB = BN + 32;
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][TBK * LDA];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TBK * LDB];
+  constexpr int NBUF = TN_NBUF;                               // 1: half the LDS, twice the workgroups per CU, one more barrier per k tile
+  __shared__ __attribute__((aligned(16))) __bf16 As[NBUF][TBK * LDA];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[NBUF][TBK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
   int bx, by, bz;
@@ -507,10 +514,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int 
 #pragma unroll 4
       for (int kr = bias_first; kr < TBK; kr += bias_step) bsum += (float)As[buf][kr * LDA + (tid & (BM - 1))];
     }
-    if (nx < nfull) { sa.store_full(As[buf ^ 1], scaled); sb.store_full(Bs[buf ^ 1], false); }
-    else if (nx < ntiles) { sa.store_tail(As[buf ^ 1], scaled, kn, kend); sb.store_tail(Bs[buf ^ 1], false, kn, kend); }
+    const int nb = NBUF == 2 ? buf ^ 1 : 0;
+    if (NBUF == 1) __syncthreads();                           // every wave is done reading the single buffer
+    if (nx < nfull) { sa.store_full(As[nb], scaled); sb.store_full(Bs[nb], false); }
+    else if (nx < ntiles) { sa.store_tail(As[nb], scaled, kn, kend); sb.store_tail(Bs[nb], false, kn, kend); }
     __syncthreads();
-    buf ^= 1;
+    buf = nb;
   }
   float* C = static_cast<float*>(g.C);
   const int how = part ? 0 : (ksplit == 1 ? 1 : 2);
@@ -651,7 +660,7 @@ int launch_tn(const WmGemm& g, hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
   const int64_t mn = (int64_t)g.M * g.N;
   const bool use_part = g.scratch && !(g.N & 3);
-  int ksplit = g.ksplit > 0 ? g.ksplit : ((use_part ? 384 : 768) + tiles - 1) / tiles;
+  int ksplit = g.ksplit > 0 ? g.ksplit : ((use_part ? TN_TARGET : 768) + tiles - 1) / tiles;
   const int maxs = (g.K + (use_part ? 127 : 255)) / (use_part ? 128 : 256);
   if (ksplit > maxs) ksplit = maxs;
   if (use_part && (int64_t)ksplit * mn > g.scratch_floats) ksplit = (int)(g.scratch_floats / mn);
