@@ -119,3 +119,32 @@ def test_gradsync_two_ranks_gloo(wm, tmp_path):
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_small_model_mirrors_keep_the_reference_state_dict_layout(wm):
+    """Rows A18 / A19: ModelA and the HiDDeN decoder mirror the reference's parameter / buffer names and shapes."""
+    from oracle import uformer_wm as O
+    for ours, ref in ((wm.ModelA(), O.ModelA()), (wm.HiddenDecoder(64, 7, 30), O.HiddenDecoder(64, 7, 30))):
+        a, b = ours.state_dict(), ref.state_dict()
+        assert list(a.keys()) == list(b.keys())
+        assert all(a[k].shape == b[k].shape for k in b)
+    with pytest.raises(wm.WmKernelError):                       # no CPU fallback for these either
+        wm.ModelA()(torch.zeros(1, 2, 128, 128), torch.zeros(1, 1, 32, 32))
+    assert wm.decoded_ber(torch.tensor([[0.2, 0.7], [1.4, -0.3]]), torch.tensor([[0.0, 1.0], [1.0, 1.0]])) == 0.25
+
+
+def test_payload_quadrant_tiling_is_a_pure_permutation(wm):
+    """Row A14 (config 5): 64x64 payload <-> four 32x32 quadrants over the tiles of a clip (host-side index math)."""
+    dp = wm.dataprep
+    img = torch.arange(2 * 64 * 64, dtype=torch.float32).reshape(2, 1, 64, 64)
+    q = dp.split_payload(img)
+    assert q.shape == (2, 4, 1, 32, 32)
+    assert torch.equal(q[:, 0, 0], img[:, 0, :32, :32]) and torch.equal(q[:, 3, 0], img[:, 0, 32:, 32:])
+    assert torch.equal(dp.merge_payload(q), img)
+    per_tile = dp.payload_for_tiles(img, 10)
+    assert per_tile.shape == (20, 1, 32, 32) and torch.equal(per_tile[10 + 6], q[1, 2])
+    assert torch.equal(dp.payload_from_tiles(per_tile, 10), img)
+    with pytest.raises(ValueError):
+        dp.split_payload(torch.zeros(1, 1, 32, 32))
+    with pytest.raises(ValueError):
+        dp.payload_from_tiles(torch.zeros(3, 1, 32, 32), 3)
