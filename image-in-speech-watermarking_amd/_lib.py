@@ -13,6 +13,11 @@ c_f = C.c_void_p          # device float*
 c_i32, c_i64, c_u64, c_fl = C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
 
+class WmReduceJob(C.Structure):
+    _fields_ = [("src", c_f), ("pstride", c_i64), ("src_ld", c_i64), ("count", c_i32), ("rows", c_i32), ("cols", c_i32),
+                ("reserved", c_i32), ("dst", c_f), ("dst_rs", c_i64), ("dst_cs", c_i64)]
+
+
 class WmGemm(C.Structure):
     _fields_ = [("A", c_f), ("B", c_f), ("C", c_f),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32),
@@ -25,7 +30,7 @@ class WmGemm(C.Structure):
                 ("b_ones", c_i32), ("C2", c_f),
                 ("atomic_out", c_i32), ("ksplit", c_i32), ("mode", c_i32),
                 ("a_bf16", c_i32), ("b_bf16", c_i32), ("c_bf16", c_i32), ("gaux_bf16", c_i32),
-                ("gaux_raw", c_i32), ("scratch", c_f), ("scratch_floats", c_i64)]
+                ("gaux_raw", c_i32), ("scratch", c_f), ("scratch_floats", c_i64), ("defer", C.POINTER(WmReduceJob))]
 
 
 class WmConv(C.Structure):
@@ -44,13 +49,14 @@ _SIGS = {
     "wm_gemm": [C.POINTER(WmGemm), c_f],
     "wm_layernorm_fwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f],
     "wm_layernorm_bwd_scratch_floats": [c_i32],
-    "wm_layernorm_bwd": [c_f, c_i32] + [c_f] * 10 + [c_i64, c_i32, c_i32, c_i32, c_f],
+    "wm_reduce_jobs": [C.POINTER(WmReduceJob), c_i32, c_f],
+    "wm_layernorm_bwd": [c_f, c_i32] + [c_f] * 10 + [C.POINTER(WmReduceJob), c_i64, c_i32, c_i32, c_i32, c_f],
     "wm_winattn_fwd": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_winattn_bwd_scratch_floats": [],
-    "wm_winattn_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_winattn_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.POINTER(WmReduceJob), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_dwconv_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_dwconv_bwd_scratch_floats": [c_i32, c_i32, c_i32],
-    "wm_dwconv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_dwconv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.POINTER(WmReduceJob), c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_im2col_4x4s2": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_col2im_4x4s2": [c_f, c_i32, c_f, c_i32, c_i32, c_i32, c_f],
     "wm_pixel_shuffle2": [c_f, c_i32, c_f, c_f, c_i32, c_i32, c_i32, c_i64, c_i32, c_f],

@@ -14,7 +14,8 @@
 int wm_attn_fast_fwd(const __bf16* qkv, const float* table, __bf16* out, float* lse, int B, int hw, int C, int shift,
                      hipStream_t st);
 int wm_attn_fast_bwd(const __bf16* qkv, const float* table, const __bf16* out, const float* lse, const __bf16* dout,
-                     __bf16* dqkv, float* dtable, float* scratch, int B, int hw, int C, int shift, hipStream_t st);
+                     __bf16* dqkv, float* dtable, float* scratch, WmReduceJob* defer, int B, int hw, int C, int shift,
+                     hipStream_t st);
 
 namespace {
 
@@ -325,15 +326,17 @@ extern "C" int wm_winattn_fwd(const void* qkv, const float* bias_table, void* ou
 extern "C" int64_t wm_winattn_bwd_scratch_floats(void) { return 1024 * 232; }
 
 extern "C" int wm_winattn_bwd(const void* qkv, const float* bias_table, const void* out, const float* lse,
-                              const void* dout, void* dqkv, float* dbias_table, float* scratch, int32_t io_bf16,
-                              int32_t B, int32_t hw, int32_t C, int32_t shift, int32_t mode, void* stream) {
+                              const void* dout, void* dqkv, float* dbias_table, float* scratch, WmReduceJob* defer,
+                              int32_t io_bf16, int32_t B, int32_t hw, int32_t C, int32_t shift, int32_t mode,
+                              void* stream) {
+  if (defer) *defer = WmReduceJob{};                           // count 0 unless the fast path defers its bias-table reduction
   if (!geom_ok(qkv, bias_table, B, hw, C, shift) || !dout || !dqkv || !dbias_table || (io_bf16 && mode != 1))
     return WM_EINVAL;
   WinGeom g{hw, shift, hw / 8, C, C / 32};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (mode == 1 && io_bf16 && out && lse)                 // forward output + row log-sum-exp available: attn_fast.hip
     return wm_attn_fast_bwd(static_cast<const __bf16*>(qkv), bias_table, static_cast<const __bf16*>(out), lse,
-                            static_cast<const __bf16*>(dout), static_cast<__bf16*>(dqkv), dbias_table, scratch, B, hw, C, shift, st);
+                            static_cast<const __bf16*>(dout), static_cast<__bf16*>(dqkv), dbias_table, scratch, defer, B, hw, C, shift, st);
   if (mode == 0) return attn_bwd_launch<float, float>(qkv, bias_table, dout, dqkv, dbias_table, g, B, st);
   if (mode == 1 && io_bf16) return attn_bwd_launch<__bf16, __bf16>(qkv, bias_table, dout, dqkv, dbias_table, g, B, st);
   if (mode == 1) return attn_bwd_launch<__bf16, float>(qkv, bias_table, dout, dqkv, dbias_table, g, B, st);

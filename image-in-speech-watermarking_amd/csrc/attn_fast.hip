@@ -15,6 +15,7 @@
 //    Accumulator-as-operand: k slot (h, j) of a 16-deep step s carries row 16s + 8(j>>2) + 4h + (j&3); the A operand is
 //    fetched with the matching permuted transposing LDS read (ds_read_b64_tr_b16).
 #include "common.h"
+#include "../../include/wm_kernels.h"
 
 namespace {
 
@@ -412,7 +413,8 @@ int wm_attn_fast_fwd(const __bf16* qkv, const float* table, __bf16* out, float* 
 }
 
 int wm_attn_fast_bwd(const __bf16* qkv, const float* table, const __bf16* out, const float* lse, const __bf16* dout,
-                     __bf16* dqkv, float* dtable, float* scratch, int B, int hw, int C, int shift, hipStream_t st) {
+                     __bf16* dqkv, float* dtable, float* scratch, WmReduceJob* defer, int B, int hw, int C, int shift,
+                     hipStream_t st) {
   Geom g{hw, shift, hw / 8, C, C / 32};
   const int nwin = B * g.nw * g.nw;
   int blocks, nchunk;
@@ -420,6 +422,15 @@ int wm_attn_fast_bwd(const __bf16* qkv, const float* table, const __bf16* out, c
   hipLaunchKernelGGL(attn_bwd_fast_kernel, dim3(blocks), dim3(64), 0, st, qkv, table, out, lse, dout, dqkv, dtable, scratch, g,
                      nwin, nchunk);
   WM_CHECK_LAUNCH();
+  if (defer) {                                                // one entry: dtable[t][head] out of part[chunk][head][232]
+    WmReduceJob jb{};
+    if (scratch) {
+      jb.src = scratch; jb.pstride = (int64_t)g.heads * 232; jb.src_ld = 232; jb.count = nchunk; jb.rows = g.heads; jb.cols = 225;
+      jb.dst = dtable; jb.dst_rs = 1; jb.dst_cs = g.heads;
+    }
+    *defer = jb;
+    if (scratch) return WM_OK;
+  }
   if (scratch) {
     int segs = nchunk / 16 < 1 ? 1 : (nchunk / 16 > 32 ? 32 : nchunk / 16);
     const int per = (nchunk + segs - 1) / segs;

@@ -318,7 +318,8 @@ extern "C" int64_t wm_dwconv_bwd_scratch_floats(int32_t B, int32_t hw, int32_t C
 }
 
 extern "C" int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, void* dh1, float* dw, float* db,
-                             float* scratch, int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream) {
+                             float* scratch, WmReduceJob* defer, int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch,
+                             void* stream) {
   if (!h1 || !dh2 || !w || !dh1 || !dw || !db || !ok(B, hw, Ch)) return WM_EINVAL;
   const int nt = hw / TP;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -329,6 +330,19 @@ extern "C" int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, vo
     hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(B * nt, Ch / TC), dim3(256), 0, st, static_cast<const float*>(h1),
                        static_cast<const float*>(dh2), w, static_cast<float*>(dh1), dw, db, scratch, B, hw, Ch);
   WM_CHECK_LAUNCH();
+  if (defer) {                                                // two entries: dw [Ch][9], db [Ch] out of part[p][Ch][10]
+    WmReduceJob jb{};
+    defer[0] = jb;
+    defer[1] = jb;
+    if (scratch) {
+      jb.src = scratch; jb.pstride = (int64_t)Ch * 10; jb.src_ld = 10; jb.count = B * nt; jb.rows = Ch; jb.cols = 9;
+      jb.dst = dw; jb.dst_rs = 9; jb.dst_cs = 1;
+      defer[0] = jb;
+      jb.src = scratch + 9; jb.cols = 1; jb.dst = db; jb.dst_rs = 1;
+      defer[1] = jb;
+      return WM_OK;
+    }
+  }
   if (scratch) {
     const int P = B * nt;
     int segs = P / 8 < 1 ? 1 : (P / 8 > 32 ? 32 : P / 8);

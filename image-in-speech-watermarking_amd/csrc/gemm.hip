@@ -578,6 +578,7 @@ extern "C" int64_t wm_gemm_scratch_floats(void) { return 384LL * 128 * 128 + 102
 extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
   if (!gp) return WM_EINVAL;
   const WmGemm& g = *gp;
+  if (g.defer) *g.defer = WmReduceJob{};                       // count 0: nothing deferred unless the split-K path fills it in
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A || !g.B || !g.C) return WM_EINVAL;
   const int amask = g.a_bf16 ? 7 : 3, bmask = g.b_bf16 ? 7 : 3;
   if (!al16(g.A) || !al16(g.B) || (g.lda & amask) || (g.ldb & bmask)) return WM_EINVAL;

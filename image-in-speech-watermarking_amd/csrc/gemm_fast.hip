@@ -672,6 +672,15 @@ int launch_tn(const WmGemm& g, hipStream_t st) {
   hipLaunchKernelGGL((gemm_tn_kernel<AT, BT, B_GELU, TM, TN>), dim3(8 * ((ksplit + 7) / 8) * tiles), dim3(256), 0, st, g, klen,
                      tiles_n, tiles_m, ksplit, part);
   WM_CHECK_LAUNCH();
+  if (g.defer) {                                              // the caller sums the slices later (wm_reduce_jobs)
+    WmReduceJob jb{};
+    if (part) {
+      jb.src = part; jb.pstride = mn; jb.src_ld = g.N; jb.count = ksplit; jb.rows = g.M; jb.cols = g.N;
+      jb.dst = static_cast<float*>(g.C); jb.dst_rs = g.ldc; jb.dst_cs = 1;
+    }
+    *g.defer = jb;
+    return WM_OK;
+  }
   if (part) {
     const int64_t blocks = (mn / 4 + 255) / 256;
     int segs = (int)(256 / blocks);
@@ -698,6 +707,7 @@ int dispatch_tn(const WmGemm& g, hipStream_t st) {
 
 // Returns -1 when the launch does not fit the fast kernels (caller falls back to the generic kernel of gemm.hip).
 int wm_gemm_fast_bf16(const WmGemm& g, hipStream_t st) {
+  if (g.defer) *g.defer = WmReduceJob{};                       // count 0 unless a split-K launch fills it in
   if (g.mode != 1 || getenv("WM_NO_FAST")) return -1;
   const int ea = g.a_bf16 ? 8 : 4, eb = g.b_bf16 ? 8 : 4;
   if (!g.a_kc && !g.b_kc && g.atomic_out && !g.a_op && !g.c_bf16) {          // weight gradient

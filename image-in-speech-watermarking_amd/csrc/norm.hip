@@ -230,7 +230,7 @@ int ln_fwd_launch(const float* x, const float* g, const float* b, const float* m
 }
 template <int C>
 int ln_bwd_launch(const void* dy, int dy_bf16, const float* x, const float* g, const float* mean, const float* rstd,
-                  const float* dres, float* dx, float* dg, float* db, float* scratch, int64_t rows, hipStream_t st) {
+                  const float* dres, float* dx, float* dg, float* db, float* scratch, WmReduceJob* defer, int64_t rows, hipStream_t st) {
   constexpr int L = (C / 4 < 64) ? C / 4 : 64;
   constexpr int RPB = LNB_WAVES * (64 / L);
   int64_t blocks = (rows + RPB - 1) / RPB;
@@ -242,6 +242,19 @@ int ln_bwd_launch(const void* dy, int dy_bf16, const float* x, const float* g, c
     hipLaunchKernelGGL((ln_bwd_kernel<C, float>), dim3((unsigned)blocks), dim3(512), 0, st,
                        static_cast<const float*>(dy), x, g, mean, rstd, dres, dx, dg, db, scratch, rows);
   WM_CHECK_LAUNCH();
+  if (defer) {                                                // two entries: dgamma, dbeta
+    WmReduceJob jb{};
+    defer[0] = jb;
+    defer[1] = jb;
+    if (scratch) {
+      jb.src = scratch; jb.pstride = 2 * C; jb.src_ld = C; jb.count = (int)blocks; jb.rows = 1; jb.cols = C;
+      jb.dst = dg; jb.dst_rs = C; jb.dst_cs = 1;
+      defer[0] = jb;
+      jb.src = scratch + C; jb.dst = db;
+      defer[1] = jb;
+      return WM_OK;
+    }
+  }
   if (scratch) {
     const int P = (int)blocks;
     int segs = P / 8 < 1 ? 1 : (P / 8 > 32 ? 32 : P / 8);
@@ -275,18 +288,18 @@ extern "C" int64_t wm_layernorm_bwd_scratch_floats(int32_t C) { return 512LL * 2
 
 extern "C" int wm_layernorm_bwd(const void* dy, int32_t dy_bf16, const float* x, const float* gamma, const float* mean,
                                 const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                                float* dmod, float* scratch, int64_t rows, int32_t C, int32_t hw, int32_t shift,
-                                void* stream) {
+                                float* dmod, float* scratch, WmReduceJob* defer, int64_t rows, int32_t C, int32_t hw,
+                                int32_t shift, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return WM_EINVAL;
   if (dmod && (hw <= 0 || (hw & 7) || rows % ((int64_t)hw * hw) || C < 64 || C > 1024)) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
   switch (C) {
-    case 32: rc = ln_bwd_launch<32>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, rows, st); break;
-    case 64: rc = ln_bwd_launch<64>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, rows, st); break;
-    case 128: rc = ln_bwd_launch<128>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, rows, st); break;
-    case 256: rc = ln_bwd_launch<256>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, rows, st); break;
-    case 512: rc = ln_bwd_launch<512>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, rows, st); break;
+    case 32: rc = ln_bwd_launch<32>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, defer, rows, st); break;
+    case 64: rc = ln_bwd_launch<64>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, defer, rows, st); break;
+    case 128: rc = ln_bwd_launch<128>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, defer, rows, st); break;
+    case 256: rc = ln_bwd_launch<256>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, defer, rows, st); break;
+    case 512: rc = ln_bwd_launch<512>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, defer, rows, st); break;
     default: return WM_EINVAL;
   }
   if (rc) return rc;

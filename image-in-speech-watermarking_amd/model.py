@@ -298,6 +298,24 @@ class UformerAudio(nn.Module):
     def _gemm_scratch(self, dev):
         return self._scratch(dev, ops.lib.wm_gemm_scratch_floats())
 
+    def _block_scratch(self, dev, B, hw, C):
+        """Eight disjoint scratch slices for the deferred reductions of one LeWin block's backward (4 split-K GEMMs, 2
+        LayerNorms, depthwise conv, attention bias table) + the host-side job list; one launch sums them all."""
+        sizes = [int(ops.lib.wm_gemm_scratch_floats())] * 4 + [int(ops.lib.wm_layernorm_bwd_scratch_floats(C))] * 2 + \
+                [int(ops.lib.wm_dwconv_bwd_scratch_floats(B, hw, 4 * C)), int(ops.lib.wm_winattn_bwd_scratch_floats())]
+        sizes = [(n + 63) // 64 * 64 for n in sizes]
+        buf = getattr(self, "_blk_scr", None)
+        if buf is None or buf.device != dev or buf.numel() < sum(sizes):
+            buf = self._blk_scr = torch.empty(sum(sizes), device=dev)
+        out, off = [], 0
+        for n in sizes:
+            out.append(buf[off:off + n])
+            off += n
+        jobs = getattr(self, "_jobs", None)
+        if jobs is None:
+            jobs = self._jobs = ops.ReduceJobs()
+        return out, jobs
+
     def _attn_scratch(self, dev):
         return self._scratch(dev, ops.lib.wm_winattn_bwd_scratch_floats())
 
@@ -401,38 +419,41 @@ class UformerAudio(nn.Module):
         (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2, lse) = sv
         P, G, dev, mode = self._views, self._gviews, x.device, self._mode()
         M, N = x.shape[0], hw * hw
+        # every small-gradient reduction of the block (4 split-K, 2 LN, depthwise, bias table) is deferred into one launch
+        (sg0, sg1, sg2, sg3, sl0, sl1, sdw, sat), jobs = self._block_scratch(dev, B, hw, C)
         # LeFF
         H, W = self._H, self._W
         dh2 = H(dev, M, 4 * C)
         ops.linear_bwd_input(dy, W(pre + "mlp.linear2.0.weight"), dh2, mode, rowscale=s2, rows_per_scale=N, gaux=h2, gaux_raw=True)
         ops.linear_bwd_weight(dy, a2, G[pre + "mlp.linear2.0.weight"], G[pre + "mlp.linear2.0.bias"], mode,
-                              kscale=s2, k_per_scale=N, scratch=self._gemm_scratch(dev))
+                              kscale=s2, k_per_scale=N, scratch=sg0, defer=jobs.take(1))
         dh1 = H(dev, M, 4 * C)
         ops.dwconv_bwd(h1, dh2, P[pre + "mlp.dwconv.0.weight"], dh1, G[pre + "mlp.dwconv.0.weight"],
-                       G[pre + "mlp.dwconv.0.bias"], B, hw, 4 * C,
-                       scratch=self._scratch(dev, ops.lib.wm_dwconv_bwd_scratch_floats(B, hw, 4 * C)))
+                       G[pre + "mlp.dwconv.0.bias"], B, hw, 4 * C, scratch=sdw, defer=jobs.take(2))
         dxn2 = H(dev, M, C)
         ops.linear_bwd_input(dh1, W(pre + "mlp.linear1.0.weight"), dxn2, mode)
-        ops.linear_bwd_weight(dh1, xn2, G[pre + "mlp.linear1.0.weight"], G[pre + "mlp.linear1.0.bias"], mode, scratch=self._gemm_scratch(dev))
+        ops.linear_bwd_weight(dh1, xn2, G[pre + "mlp.linear1.0.weight"], G[pre + "mlp.linear1.0.bias"], mode, scratch=sg1,
+                              defer=jobs.take(1))
         dx1 = _E(dev, M, C)
         ops.layernorm_bwd(dxn2, x1, P[pre + "norm2.weight"], mean2, rstd2, dy, dx1, G[pre + "norm2.weight"],
-                          G[pre + "norm2.bias"], None, hw, 0,
-                          scratch=self._scratch(dev, ops.lib.wm_layernorm_bwd_scratch_floats(C)))
+                          G[pre + "norm2.bias"], None, hw, 0, scratch=sl0, defer=jobs.take(2))
         # attention
         do = dxn2                                                  # reuse buffer
         ops.linear_bwd_input(dx1, W(pre + "attn.proj.weight"), do, mode, rowscale=s1, rows_per_scale=N)
-        ops.linear_bwd_weight(dx1, o, G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], mode, kscale=s1, k_per_scale=N, scratch=self._gemm_scratch(dev))
+        ops.linear_bwd_weight(dx1, o, G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], mode, kscale=s1, k_per_scale=N,
+                              scratch=sg2, defer=jobs.take(1))
         dqkv = H(dev, M, 3 * C)
         ops.winattn_bwd(qkv, P[pre + "attn.relative_position_bias_table"], do, dqkv,
                         G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, mode, out=o, lse=lse,
-                        scratch=self._attn_scratch(dev))
+                        scratch=sat, defer=jobs.take(1))
         dxn1 = H(dev, M, C)
         ops.linear_bwd_input(dqkv, W(pre + "attn.qkv.w"), dxn1, mode)
-        ops.linear_bwd_weight(dqkv, xn1, G[pre + "attn.qkv.w"], G[pre + "attn.qkv.b"], mode, scratch=self._gemm_scratch(dev))
+        ops.linear_bwd_weight(dqkv, xn1, G[pre + "attn.qkv.w"], G[pre + "attn.qkv.b"], mode, scratch=sg3, defer=jobs.take(1))
         dx = _E(dev, M, C)
         ops.layernorm_bwd(dxn1, x, P[pre + "norm1.weight"], mean1, rstd1, dx1, dx, G[pre + "norm1.weight"],
                           G[pre + "norm1.bias"], G[pre + "modulator.weight"] if mod else None, hw, shift,
-                          scratch=self._scratch(dev, ops.lib.wm_layernorm_bwd_scratch_floats(C)))
+                          scratch=sl1, defer=jobs.take(2))
+        ops.reduce_jobs(jobs)
         return dx
 
     def _down_fwd(self, pre, x, B, hw, C):

@@ -8,7 +8,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, check, ptr, WmGemm, WmConv, WmAttack
+from ._lib import lib, check, ptr, WmGemm, WmConv, WmAttack, WmReduceJob
 
 MODE_FP32, MODE_BF16 = 0, 1
 
@@ -30,11 +30,11 @@ def _bf(t):
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=1, b_kc=1, a_op=0, b_op=0, bias=None, res=None, ldr=0,
          rowscale=None, rows_per_scale=0, kscale=None, k_per_scale=0, gaux=None, ldg=0, b_ones=False, C2=None,
-         atomic_out=False, ksplit=0, mode=MODE_FP32, gaux_raw=False, scratch=None):
+         atomic_out=False, ksplit=0, mode=MODE_FP32, gaux_raw=False, scratch=None, defer=None):
     g = WmGemm(ptr(A), ptr(B), ptr(Cout), M, N, K, lda, ldb, ldc, a_kc, b_kc, a_op, b_op, ptr(bias), ptr(res), ldr,
                ptr(rowscale), rows_per_scale, ptr(kscale), k_per_scale, ptr(gaux), ldg, int(b_ones), ptr(C2),
                int(atomic_out), ksplit, mode, _bf(A), _bf(B), _bf(Cout), _bf(gaux), int(gaux_raw),
-               ptr(scratch), scratch.numel() if scratch is not None else 0)
+               ptr(scratch), scratch.numel() if scratch is not None else 0, defer)
     check(lib.wm_gemm(C.byref(g), _stream()), f"wm_gemm(M={M},N={N},K={K})")
 
 
@@ -54,12 +54,12 @@ def linear_bwd_input(dy, w, dx, mode, rowscale=None, rows_per_scale=0, gaux=None
          mode=mode, gaux_raw=gaux_raw)
 
 
-def linear_bwd_weight(dy, x, dw, db, mode, x_op=0, kscale=None, k_per_scale=0, scratch=None):
+def linear_bwd_weight(dy, x, dw, db, mode, x_op=0, kscale=None, k_per_scale=0, scratch=None, defer=None):
     """dw[N,K] += (dy*kscale)^T[N,M] @ op(x)[M,K];  db[N] += column sums of dy*kscale"""
     M, N = dy.shape
     K = x.shape[1]
     gemm(dy, x, dw, N, K, M, N, K, K, 0, 0, b_op=x_op, kscale=kscale, k_per_scale=k_per_scale,
-         b_ones=db is not None, C2=db, atomic_out=True, mode=mode, scratch=scratch)
+         b_ones=db is not None, C2=db, atomic_out=True, mode=mode, scratch=scratch, defer=defer)
 
 
 def layernorm_fwd(x, gamma, beta, mod, y, mean, rstd, hw, shift):
@@ -68,12 +68,12 @@ def layernorm_fwd(x, gamma, beta, mod, y, mean, rstd, hw, shift):
                                hw, shift, _stream()), "wm_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dmod, hw, shift, scratch=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dmod, hw, shift, scratch=None, defer=None):
     rows, Cc = x.shape
     if scratch is not None and scratch.numel() < lib.wm_layernorm_bwd_scratch_floats(Cc):
         raise ValueError("layernorm_bwd: scratch buffer too small")
     check(lib.wm_layernorm_bwd(ptr(dy), _bf(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
-                               ptr(dgamma), ptr(dbeta), ptr(dmod), ptr(scratch), rows, Cc, hw, shift, _stream()),
+                               ptr(dgamma), ptr(dbeta), ptr(dmod), ptr(scratch), defer, rows, Cc, hw, shift, _stream()),
           "wm_layernorm_bwd")
 
 
@@ -84,13 +84,13 @@ def winattn_fwd(qkv, table, out, B, hw, Cc, shift, mode, lse=None):
           "wm_winattn_fwd")
 
 
-def winattn_bwd(qkv, table, dout, dqkv, dtable, B, hw, Cc, shift, mode, out=None, lse=None, scratch=None):
+def winattn_bwd(qkv, table, dout, dqkv, dtable, B, hw, Cc, shift, mode, out=None, lse=None, scratch=None, defer=None):
     if scratch is not None and scratch.numel() < lib.wm_winattn_bwd_scratch_floats():
         raise ValueError("winattn_bwd: scratch buffer too small")
     if not (_bf(qkv) == _bf(dout) == _bf(dqkv)) or (out is not None and _bf(out) != _bf(qkv)):
         raise ValueError("winattn_bwd: qkv, out, dout and dqkv must share a storage type")
     check(lib.wm_winattn_bwd(ptr(qkv), ptr(table), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), ptr(dtable), ptr(scratch),
-                             _bf(qkv), B, hw, Cc, shift, mode, _stream()), "wm_winattn_bwd")
+                             defer, _bf(qkv), B, hw, Cc, shift, mode, _stream()), "wm_winattn_bwd")
 
 
 def dwconv_fwd(h1, w, b, h2, B, hw, Ch, a2=None, g2=None):
@@ -102,12 +102,12 @@ def dwconv_fwd(h1, w, b, h2, B, hw, Ch, a2=None, g2=None):
           "wm_dwconv_fwd")
 
 
-def dwconv_bwd(h1, dh2, w, dh1, dw, db, B, hw, Ch, scratch=None):
+def dwconv_bwd(h1, dh2, w, dh1, dw, db, B, hw, Ch, scratch=None, defer=None):
     if not (_bf(h1) == _bf(dh2) == _bf(dh1)):
         raise ValueError("dwconv_bwd: h1, dh2 and dh1 must share a storage type")
     if scratch is not None and scratch.numel() < lib.wm_dwconv_bwd_scratch_floats(B, hw, Ch):
         raise ValueError("dwconv_bwd: scratch buffer too small")
-    check(lib.wm_dwconv_bwd(ptr(h1), ptr(dh2), ptr(w), ptr(dh1), ptr(dw), ptr(db), ptr(scratch), _bf(h1), B, hw, Ch,
+    check(lib.wm_dwconv_bwd(ptr(h1), ptr(dh2), ptr(w), ptr(dh1), ptr(dw), ptr(db), ptr(scratch), defer, _bf(h1), B, hw, Ch,
                             _stream()), "wm_dwconv_bwd")
 
 
@@ -268,3 +268,30 @@ def zero_(t):
     """t[...] = 0 with a libwm_hip kernel (a kernel node in captured steps; no ATen fill on the hot path)."""
     check(lib.wm_zero(ptr(t), t.numel(), _stream()), "wm_zero")
     return t
+
+
+class ReduceJobs:
+    """Host-side list of deferred partial-sum reductions (WmReduceJob x 16) that one wm_reduce_jobs launch performs.
+    ``take(k)`` hands the next k entries to a producer's ``defer`` argument; ``run()`` launches and empties the list."""
+
+    CAP = 16
+
+    def __init__(self):
+        self.arr = (WmReduceJob * self.CAP)()
+        self.n = 0
+
+    def take(self, k):
+        if self.n + k > self.CAP:
+            raise ValueError("ReduceJobs is full")
+        p = C.cast(C.byref(self.arr, self.n * C.sizeof(WmReduceJob)), C.POINTER(WmReduceJob))
+        self.n += k
+        return p
+
+    def run(self):
+        if self.n:
+            check(lib.wm_reduce_jobs(self.arr, self.n, _stream()), "wm_reduce_jobs")
+        self.n = 0
+
+
+def reduce_jobs(jobs):
+    jobs.run()

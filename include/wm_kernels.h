@@ -31,6 +31,19 @@ int wm_abi_version(void);
  * LinearProjection (model.py:460-471), WindowAttention.proj (:549), LeFF.linear1/2 (:700,711),
  * Downsample/Upsample as im2col GEMMs (:763,789) and their autograd backward.
  */
+/* ---- deferred partial-sum reductions ------------------------------------------------------------------------
+ * Kernels that accumulate small parameter gradients from many workgroups store per-workgroup partial sums to a scratch
+ * buffer and normally launch a small reduce kernel right away.  Given a `defer` pointer they instead describe that
+ * reduction in WmReduceJob entries (their scratch slice must then stay untouched) and ONE wm_reduce_jobs() call performs
+ * up to 16 of them: dst(r, c) += sum_p src[p * pstride + r * src_ld + c], r < rows, c < cols, p < count, with
+ * dst(r, c) at dst[r * dst_rs + c * dst_cs].  count == 0 marks an entry whose producer had nothing to defer.           */
+typedef struct WmReduceJob {
+  const float* src; int64_t pstride; int64_t src_ld;
+  int32_t count, rows, cols, reserved;
+  float* dst; int64_t dst_rs, dst_cs;
+} WmReduceJob;
+int wm_reduce_jobs(const WmReduceJob* jobs, int32_t njobs, void* stream);
+
 typedef struct WmGemm {
   const void* A; const void* B; void* C;    /* fp32, or bf16 where the *_bf16 flag below is set (mode 1 only)      */
   int32_t M, N, K;
@@ -51,6 +64,7 @@ typedef struct WmGemm {
   int32_t gaux_raw;          /* 1: gaux already holds the factor (gelu'(h2) saved by wm_dwconv_fwd): plain multiply  */
   float* scratch;            /* optional device workspace for split-K partial tiles (weight gradients, mode 1); NULL =  */
   int64_t scratch_floats;    /* fp32 atomics into C.  wm_gemm_scratch_floats() is always enough; contents irrelevant    */
+  WmReduceJob* defer;        /* optional HOST pointer to 1 entry: the split-K reduction is described there, not launched */
 } WmGemm;
 int64_t wm_gemm_scratch_floats(void);
 int wm_gemm(const WmGemm* g, void* stream);
@@ -65,7 +79,8 @@ int wm_layernorm_fwd(const float* x, const float* gamma, const float* beta, cons
 int64_t wm_layernorm_bwd_scratch_floats(int32_t C);
 int wm_layernorm_bwd(const void* dy, int32_t dy_bf16, const float* x, const float* gamma, const float* mean,
                      const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                     float* dmod, float* scratch, int64_t rows, int32_t C, int32_t hw, int32_t shift, void* stream);
+                     float* dmod, float* scratch, WmReduceJob* defer /* 2 entries or NULL */, int64_t rows, int32_t C,
+                     int32_t hw, int32_t shift, void* stream);
 
 /* ---- 8x8 window attention — model.py:523-551 with roll/partition/reverse (:987-1013) and the
  * shift mask (:954-972) folded into the indexing.  qkv: [B*hw*hw, 3C] (q|k|v), heads of 32.    */
@@ -78,8 +93,8 @@ int wm_winattn_fwd(const void* qkv, const float* bias_table, void* out, float* l
  * sums of the relative-position-bias gradient, reduced by a second kernel; NULL = global atomics (slower).        */
 int64_t wm_winattn_bwd_scratch_floats(void);
 int wm_winattn_bwd(const void* qkv, const float* bias_table, const void* out, const float* lse, const void* dout,
-                   void* dqkv, float* dbias_table, float* scratch, int32_t io_bf16, int32_t B, int32_t hw, int32_t C,
-                   int32_t shift, int32_t mode, void* stream);
+                   void* dqkv, float* dbias_table, float* scratch, WmReduceJob* defer /* 1 entry or NULL */, int32_t io_bf16,
+                   int32_t B, int32_t hw, int32_t C, int32_t shift, int32_t mode, void* stream);
 
 /* ---- LeFF depthwise 3x3 on token-major [B,hw,hw,Ch] — model.py:703-709.  Input is the
  * PRE-GELU linear1 output; GELU is applied while staging.  Outputs: h2 (pre-GELU, kept for gelu' in
@@ -91,7 +106,7 @@ int wm_dwconv_fwd(const void* h1, const float* w, const float* b, void* h2 /* or
  * partial sums of dw / db, reduced by a second kernel; NULL = every workgroup adds with global atomics (slower). */
 int64_t wm_dwconv_bwd_scratch_floats(int32_t B, int32_t hw, int32_t Ch);
 int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, void* dh1, float* dw, float* db, float* scratch,
-                  int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream);
+                  WmReduceJob* defer /* 2 entries or NULL */, int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream);
 
 /* ---- data movement for Downsample (conv4x4 s2 p1, model.py:763) / Upsample (convT2x2 s2, :789) */
 int wm_im2col_4x4s2(const float* x, void* cols, int32_t cols_bf16, int32_t B, int32_t hw, int32_t C, void* stream);

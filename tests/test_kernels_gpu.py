@@ -647,3 +647,49 @@ def test_payload_quadrant_tiling_roundtrip(wm):
     per_tile = dp.payload_for_tiles(img, 10)                         # 10 s clip = 10 tiles
     assert per_tile.shape == (30, 1, 32, 32) and torch.equal(per_tile[4], q[0, 0]) and torch.equal(per_tile[13], q[1, 3])
     assert torch.allclose(dp.payload_from_tiles(per_tile, 10), img)
+
+
+# ------------------------------------------------------------------------------------------- deferred reductions
+def test_deferred_reductions_match_immediate_ones(wm):
+    """wm_reduce_jobs: LayerNorm / depthwise / bias-table / split-K producers defer their partial-sum reductions into one
+    launch; gradients must equal the immediate (scratch + own reduce kernel) results."""
+    ops = wm.ops
+    B, hw, C = 2, 16, 64
+    rows, Ch, heads = B * hw * hw, 4 * 64, 2
+    bf = torch.bfloat16
+    x = dev(synth_array("jx", (rows, C)))
+    dyb = dev(synth_array("jdy", (rows, C))).to(bf)
+    gam = dev(1 + 0.1 * synth_array("jg", (C,)))
+    mean, rstd, xn = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, C, device="cuda", dtype=bf)
+    ops.layernorm_fwd(x, gam, torch.zeros_like(gam), None, xn, mean, rstd, hw, 0)
+    h1 = dev(synth_array("jh1", (B, hw, hw, Ch))).to(bf)
+    dh2 = dev(synth_array("jdh2", (B, hw, hw, Ch))).to(bf)
+    wdw = dev(0.3 * synth_array("jw", (Ch, 1, 3, 3)))
+    qkv = dev(synth_array("jqkv", (rows, 3 * C))).to(bf)
+    table = dev(0.5 * synth_array("jtab", (225, heads)))
+    o, lse = torch.empty(rows, C, device="cuda", dtype=bf), torch.empty(rows, heads, device="cuda")
+    ops.winattn_fwd(qkv, table, o, B, hw, C, 4, 1, lse=lse)
+    do = dev(synth_array("jdo", (rows, C))).to(bf)
+    dyg, xg = dev(synth_array("jgy", (rows, 96))).to(bf), dev(synth_array("jgx", (rows, C))).to(bf)
+
+    def run(deferred):
+        jobs = ops.ReduceJobs() if deferred else None
+        take = (lambda k: jobs.take(k)) if deferred else (lambda k: None)
+        scr = [torch.empty(int(n), device="cuda") for n in (wm.lib.wm_layernorm_bwd_scratch_floats(C), wm.lib.wm_dwconv_bwd_scratch_floats(B, hw, Ch),
+                                                            wm.lib.wm_winattn_bwd_scratch_floats(), wm.lib.wm_gemm_scratch_floats())]
+        dx, dg, db = torch.empty(rows, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        ops.layernorm_bwd(dyb, x, gam, mean, rstd, None, dx, dg, db, None, hw, 0, scratch=scr[0], defer=take(2))
+        dh1, dw, dbw = torch.empty_like(h1), torch.zeros(Ch, 9, device="cuda"), torch.zeros(Ch, device="cuda")
+        ops.dwconv_bwd(h1, dh2, wdw, dh1, dw, dbw, B, hw, Ch, scratch=scr[1], defer=take(2))
+        dqkv, dt = torch.empty_like(qkv), torch.zeros_like(table)
+        ops.winattn_bwd(qkv, table, do, dqkv, dt, B, hw, C, 4, 1, out=o, lse=lse, scratch=scr[2], defer=take(1))
+        gw, gb = torch.zeros(96, C, device="cuda"), torch.zeros(96, device="cuda")
+        ops.linear_bwd_weight(dyg, xg, gw, gb, 1, scratch=scr[3], defer=take(1))
+        if deferred:
+            assert jobs.n == 6
+            ops.reduce_jobs(jobs)
+            assert jobs.n == 0
+        return dg, db, dw, dbw, dt, gw, gb
+
+    for name, a, b in zip(("ln dgamma", "ln dbeta", "dw", "db", "bias table", "gemm dW", "gemm db"), run(False), run(True)):
+        assert_close(b, a, 1e-5, f"deferred {name}")
