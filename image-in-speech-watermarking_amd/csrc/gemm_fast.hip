@@ -231,8 +231,9 @@ __device__ __forceinline__ void epi_interior(const float* cs, const WmGemm& g, i
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// bf16 x bf16 instances are held to 168 registers per lane (3 waves per SIMD = 3 workgroups per CU); they need 172 unconstrained
 template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemm g, const bool vec_ok, const int tiles_n, const int tiles_m) {
+__global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 ? 3 : 2)) void gemm_nt_kernel(const WmGemm g, const bool vec_ok, const int tiles_n, const int tiles_m) {
   constexpr int BK = 64, BM = WM * TM * 32, BN = WN * TN * 32, LDA = BK + 8;
   constexpr int LDB = B_TR ? BN + 32 : BK + 8, BSZ = B_TR ? BK * LDB : BN * LDB;
   constexpr int NBUF = NT_NBUF;                              // LDS operand buffers (1: more workgroups per CU, one more barrier per k tile)
@@ -356,7 +357,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemm g, const bool
       // All epilogue operands of a group of rows (DropPath scale, gelu' factor, residual) are requested BEFORE the first
       // one is used: written as one loop the compiler waited for every load in turn, ~3 round trips per row, which
       // dominated the short-K launches.
-      constexpr int NR = PR / RPP, G = NR < 8 ? NR : 8;
+      // (specialised instances run this general code only on edge tiles: a small group keeps its operand arrays from
+      // setting the kernel's register count, which decides how many workgroups fit on a CU)
+      constexpr int NR = PR / RPP, G = EPI != 3 ? (NR < 2 ? NR : 2) : (NR < 8 ? NR : 8);
       static_assert(NR >= 1 && NR % G == 0, "rows per thread");
       const int r0 = tid / TPRW;
 #pragma unroll
