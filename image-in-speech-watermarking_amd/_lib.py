@@ -50,7 +50,7 @@ _SIGS = {
     "wm_layernorm_fwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f],
     "wm_layernorm_bwd_scratch_floats": [c_i32],
     "wm_reduce_jobs": [C.POINTER(WmReduceJob), c_i32, c_f],
-    "wm_layernorm_bwd": [c_f, c_i32] + [c_f] * 10 + [C.POINTER(WmReduceJob), c_i64, c_i32, c_i32, c_i32, c_f],
+    "wm_layernorm_bwd": [c_f, c_i32] + [c_f] * 11 + [C.POINTER(WmReduceJob), c_i64, c_i32, c_i32, c_i32, c_f],
     "wm_winattn_fwd": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_winattn_bwd_scratch_floats": [],
     "wm_winattn_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.POINTER(WmReduceJob), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],

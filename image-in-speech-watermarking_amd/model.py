@@ -415,7 +415,9 @@ class UformerAudio(nn.Module):
                        rowscale=s2, rows_per_scale=N)
         return x2, (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2, lse)
 
-    def _block_bwd(self, sv, dy):
+    def _block_bwd(self, sv, dy, dyh=None):
+        """Returns (dx, dxh): dxh is a bf16 copy of dx in bf16 mode (the next block's GEMM operand), else None.
+        dyh, if given, is such a copy of dy."""
         (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2, lse) = sv
         P, G, dev, mode = self._views, self._gviews, x.device, self._mode()
         M, N = x.shape[0], hw * hw
@@ -424,8 +426,10 @@ class UformerAudio(nn.Module):
         # LeFF
         H, W = self._H, self._W
         dh2 = H(dev, M, 4 * C)
-        ops.linear_bwd_input(dy, W(pre + "mlp.linear2.0.weight"), dh2, mode, rowscale=s2, rows_per_scale=N, gaux=h2, gaux_raw=True)
-        ops.linear_bwd_weight(dy, a2, G[pre + "mlp.linear2.0.weight"], G[pre + "mlp.linear2.0.bias"], mode,
+        half = self.compute_mode == "bf16"
+        dyg = dyh if dyh is not None else dy                       # GEMM operand: the bf16 copy when there is one
+        ops.linear_bwd_input(dyg, W(pre + "mlp.linear2.0.weight"), dh2, mode, rowscale=s2, rows_per_scale=N, gaux=h2, gaux_raw=True)
+        ops.linear_bwd_weight(dyg, a2, G[pre + "mlp.linear2.0.weight"], G[pre + "mlp.linear2.0.bias"], mode,
                               kscale=s2, k_per_scale=N, scratch=sg0, defer=jobs.take(1))
         dh1 = H(dev, M, 4 * C)
         ops.dwconv_bwd(h1, dh2, P[pre + "mlp.dwconv.0.weight"], dh1, G[pre + "mlp.dwconv.0.weight"],
@@ -435,12 +439,14 @@ class UformerAudio(nn.Module):
         ops.linear_bwd_weight(dh1, xn2, G[pre + "mlp.linear1.0.weight"], G[pre + "mlp.linear1.0.bias"], mode, scratch=sg1,
                               defer=jobs.take(1))
         dx1 = _E(dev, M, C)
+        dx1h = H(dev, M, C) if half else None
         ops.layernorm_bwd(dxn2, x1, P[pre + "norm2.weight"], mean2, rstd2, dy, dx1, G[pre + "norm2.weight"],
-                          G[pre + "norm2.bias"], None, hw, 0, scratch=sl0, defer=jobs.take(2))
+                          G[pre + "norm2.bias"], None, hw, 0, scratch=sl0, defer=jobs.take(2), dx_bf16=dx1h)
+        dx1g = dx1h if half else dx1
         # attention
         do = dxn2                                                  # reuse buffer
-        ops.linear_bwd_input(dx1, W(pre + "attn.proj.weight"), do, mode, rowscale=s1, rows_per_scale=N)
-        ops.linear_bwd_weight(dx1, o, G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], mode, kscale=s1, k_per_scale=N,
+        ops.linear_bwd_input(dx1g, W(pre + "attn.proj.weight"), do, mode, rowscale=s1, rows_per_scale=N)
+        ops.linear_bwd_weight(dx1g, o, G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], mode, kscale=s1, k_per_scale=N,
                               scratch=sg2, defer=jobs.take(1))
         dqkv = H(dev, M, 3 * C)
         ops.winattn_bwd(qkv, P[pre + "attn.relative_position_bias_table"], do, dqkv,
@@ -450,11 +456,12 @@ class UformerAudio(nn.Module):
         ops.linear_bwd_input(dqkv, W(pre + "attn.qkv.w"), dxn1, mode)
         ops.linear_bwd_weight(dqkv, xn1, G[pre + "attn.qkv.w"], G[pre + "attn.qkv.b"], mode, scratch=sg3, defer=jobs.take(1))
         dx = _E(dev, M, C)
+        dxh = H(dev, M, C) if half else None
         ops.layernorm_bwd(dxn1, x, P[pre + "norm1.weight"], mean1, rstd1, dx1, dx, G[pre + "norm1.weight"],
                           G[pre + "norm1.bias"], G[pre + "modulator.weight"] if mod else None, hw, shift,
-                          scratch=sl1, defer=jobs.take(2))
+                          scratch=sl1, defer=jobs.take(2), dx_bf16=dxh)
         ops.reduce_jobs(jobs)
-        return dx
+        return dx, dxh
 
     def _down_fwd(self, pre, x, B, hw, C):
         P, dev, mode = self._views, x.device, self._mode()
@@ -554,8 +561,11 @@ class UformerAudio(nn.Module):
         Returns the gradient w.r.t. the trunk input (image for the extractor, tokens for the encoder)."""
         G, P = self._gviews, self._views
         dy = dfeats[4] if dfeats is not None else None
+        dyh = None                                                   # bf16 copy of dy while it comes straight out of a block
         for item in reversed(tape):
             kind = item[0]
+            if kind != "block":
+                dyh = None
             if kind == "conv2":
                 _, d2, x, z = item
                 dy = _E(x.device, *x.shape)
@@ -566,7 +576,7 @@ class UformerAudio(nn.Module):
                 if dfeats is not None and dfeats[i] is not None:
                     ops.axpbyz(dy, 1.0, dy, 1.0, dfeats[i], dy.numel())
             elif kind == "block":
-                dy = self._block_bwd(item[1], dy)
+                dy, dyh = self._block_bwd(item[1], dy, dyh)
             elif kind == "inproj":
                 _, d, img, y = item
                 dimg = _E(img.device, *img.shape)
@@ -735,13 +745,14 @@ class UformerAudio(nn.Module):
         dtok = _E(dev, B * 16384, 64)
         ops.conv_bwd(d_out, ytok, P["output_proj.proj.0.weight"], noise, dy, dtok, G["output_proj.proj.0.weight"], G["output_proj.proj.0.bias"])
         dfe = [None] * 5
-        g = dtok
+        g, gh = dtok, None
         for item in reversed(S["dec"]):
             if item[0] == "block":
-                g = self._block_bwd(item[1], g)
+                g, gh = self._block_bwd(item[1], g, gh)
             else:
                 _, sv, i = item
                 g, dskip = self._up_bwd(sv, g)
+                gh = None
                 dfe[3 - i] = dskip
         if after_segment is not None:
             after_segment(1)                                        # decoder + output_proj gradients are final

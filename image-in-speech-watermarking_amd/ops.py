@@ -68,11 +68,13 @@ def layernorm_fwd(x, gamma, beta, mod, y, mean, rstd, hw, shift):
                                hw, shift, _stream()), "wm_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dmod, hw, shift, scratch=None, defer=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dmod, hw, shift, scratch=None, defer=None, dx_bf16=None):
     rows, Cc = x.shape
     if scratch is not None and scratch.numel() < lib.wm_layernorm_bwd_scratch_floats(Cc):
         raise ValueError("layernorm_bwd: scratch buffer too small")
-    check(lib.wm_layernorm_bwd(ptr(dy), _bf(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+    if dx_bf16 is not None and dx_bf16.dtype != torch.bfloat16:
+        raise ValueError("layernorm_bwd: dx_bf16 must be a bfloat16 tensor")
+    check(lib.wm_layernorm_bwd(ptr(dy), _bf(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx_bf16),
                                ptr(dgamma), ptr(dbeta), ptr(dmod), ptr(scratch), defer, rows, Cc, hw, shift, _stream()),
           "wm_layernorm_bwd")
 

@@ -77,8 +77,9 @@ int wm_layernorm_fwd(const float* x, const float* gamma, const float* beta, cons
  * scratch (optional, device, >= wm_layernorm_bwd_scratch_floats(C) floats, contents irrelevant): per-workgroup partial
  * sums of dgamma / dbeta, reduced by a second kernel; NULL = every workgroup adds with global atomics (slower).   */
 int64_t wm_layernorm_bwd_scratch_floats(int32_t C);
+/* dx_bf16 (optional): a bf16 copy of dx for the GEMMs that consume it next (they round it to bf16 anyway)           */
 int wm_layernorm_bwd(const void* dy, int32_t dy_bf16, const float* x, const float* gamma, const float* mean,
-                     const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                     const float* rstd, const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
                      float* dmod, float* scratch, WmReduceJob* defer /* 2 entries or NULL */, int64_t rows, int32_t C,
                      int32_t hw, int32_t shift, void* stream);
 

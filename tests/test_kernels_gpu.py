@@ -140,7 +140,9 @@ def test_layernorm_fwd_bwd(wm, C):
     # with a scratch buffer dgamma / dbeta are reduced by a second kernel instead of global atomics
     scr = torch.empty(int(wm.lib.wm_layernorm_bwd_scratch_floats(C)), device="cuda")
     dg2, db2 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-    ops.layernorm_bwd(dev(dy), xd, gd, mean, rstd, dev(dres), dx, dg2, db2, None, hw, shift, scratch=scr)
+    dxh = torch.empty(rows, C, device="cuda", dtype=torch.bfloat16)      # optional bf16 copy of dx for the next GEMMs
+    ops.layernorm_bwd(dev(dy), xd, gd, mean, rstd, dev(dres), dx, dg2, db2, None, hw, shift, scratch=scr, dx_bf16=dxh)
+    assert torch.equal(dxh, dx.to(torch.bfloat16))
     assert_close(dg2, gamma.grad, 1e-4, "ln dgamma (scratch)")
     assert_close(db2, beta.grad, 1e-4, "ln dbeta (scratch)")
 
