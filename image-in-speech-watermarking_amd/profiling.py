@@ -35,9 +35,9 @@ def _attn_cost(B, hw, C, products):
 COST = {
     "gemm": lambda *a, **k: _gemm_cost(a + (k,)),
     "winattn_fwd": lambda qkv, t, o, B, hw, C, sh, mode, lse=None: (_attn_cost(B, hw, C, 2), qkv.element_size() * B * hw * hw * 4.0 * C),
-    "winattn_bwd": lambda qkv, t, do, dq, dt, B, hw, C, sh, mode, out=None, lse=None, scratch=None: (_attn_cost(B, hw, C, 6), qkv.element_size() * B * hw * hw * 7.0 * C),
+    "winattn_bwd": lambda qkv, t, do, dq, dt, B, hw, C, sh, mode, out=None, lse=None, scratch=None, defer=None: (_attn_cost(B, hw, C, 6), qkv.element_size() * B * hw * hw * 7.0 * C),
     "dwconv_fwd": lambda h1, w, b, h2, B, hw, Ch, a2=None, g2=None: (18.0 * B * hw * hw * Ch, (1.0 + sum(t is not None for t in (h2, a2, g2))) * h1.element_size() * B * hw * hw * Ch),
-    "dwconv_bwd": lambda h1, d, w, dh, dw, db, B, hw, Ch, scratch=None: (54.0 * B * hw * hw * Ch, 3.0 * h1.element_size() * B * hw * hw * Ch),
+    "dwconv_bwd": lambda h1, d, w, dh, dw, db, B, hw, Ch, scratch=None, defer=None: (54.0 * B * hw * hw * Ch, 3.0 * h1.element_size() * B * hw * hw * Ch),
     "layernorm_fwd": lambda x, g, b, m, y, *a: (8.0 * x.numel(), (4.0 + y.element_size()) * x.numel()),
     "layernorm_bwd": lambda dy, x, *a, **k: (16.0 * x.numel(), (12.0 + dy.element_size()) * x.numel()),
     "im2col": lambda x, cols, *a: (0.0, 4.0 * (x.numel() + cols.numel())),
@@ -70,9 +70,9 @@ class KernelTimer:
             b_kc = args[10] if len(args) > 10 else kwargs.get("b_kc", 1)
             lay = {(1, 1): "fwd", (1, 0): "dX", (0, 0): "dW"}.get((a_kc, b_kc), "?")
             # kernel FAMILY as it appears in a rocprofv3 kernel trace: gemm_nt_kernel<...> runs forward and input-gradient
-            # GEMMs, gemm_tn_kernel<...> (+ splitk_reduce_kernel, timed together here) the weight gradients, gemm_kernel<...>
-            # is the fp32 parity-mode kernel
-            fam = "gemm_kernel(fp32)" if not mode else ("gemm_tn_kernel+splitk_reduce" if lay == "dW" else "gemm_nt_kernel")
+            # GEMMs, gemm_tn_kernel<...> the weight gradients (their split-K sums are deferred to reduce_jobs_kernel inside
+            # LeWin blocks, summed by splitk_reduce_kernel elsewhere), gemm_kernel<...> is the fp32 parity-mode kernel
+            fam = "gemm_kernel(fp32)" if not mode else ("gemm_tn_kernel" if lay == "dW" else "gemm_nt_kernel")
             if self.detail:
                 return f"{fam}_{lay}_M{M}_N{N}_K{K}", mode
             return fam, mode
@@ -154,8 +154,9 @@ def pmc_traffic(kernel_family, path):
     if not os.path.exists(path):
         return None
     fams = json.load(open(path)).get("families", {})
-    pats = {"gemm_nt_kernel": ["gemm_nt_kernel"], "gemm_tn_kernel+splitk_reduce": ["gemm_tn_kernel", "splitk_reduce_kernel"]}
-    names = pats.get(kernel_family, [kernel_family.replace("_fwd", "_fwd_kernel").replace("_bwd", "_bwd_kernel")])
+    pats = {"reduce_jobs": ["reduce_jobs_kernel"], "winattn_bwd_bf16": ["attn_bwd_fast_kernel"], "winattn_fwd_bf16": ["attn_fwd_fast_kernel"],
+            "layernorm_fwd": ["ln_fwd_kernel"], "layernorm_bwd": ["ln_bwd_kernel"]}
+    names = pats.get(kernel_family, [kernel_family if kernel_family.endswith("_kernel") else kernel_family + "_kernel"])
     tot, launches = 0.0, 0
     for nm in names:
         f = fams.get(nm)
