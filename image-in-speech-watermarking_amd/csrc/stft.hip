@@ -37,22 +37,27 @@ __device__ __forceinline__ int frames_covering(int q, int& tlo) {   // returns c
   return thi - tlo + 1;
 }
 
-// sum over frames covering OLA position q of sum_k w_k (Xr cos - Xi sin)
+// sum over frames covering OLA position q of sum_k w_k (Xr cos - Xi sin).  Twiddles and spectrum values are held as
+// (cos, sin) / (re, im) pairs so that one 8-byte LDS read feeds two multiply-adds (the loop is LDS-issue bound).
 template <bool ADJ>
-__device__ __forceinline__ float synth_at(int q, const float* Xs, int t0, const float* ct, const float* st) {
+__device__ __forceinline__ float synth_at(int q, const float2* Xs, int t0, const float2* tw) {
   int tlo;
   const int cnt = frames_covering(q, tlo);
   float total = 0.f;
   for (int f = 0; f < cnt; ++f) {
     const int t = tlo + f, n = q - HOP * t, tt = t - t0;
-    float acc = Xs[tt];                                   // k = 0: cos = 1 (imag of DC never contributes)
+    const float acc = Xs[tt].x;                           // k = 0: cos = 1 (imag of DC never contributes)
     int idx = n;                                          // k = 1
-    float a2 = 0.f;
+    float a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
     for (int k = 1; k < NBIN; ++k) {
-      a2 += Xs[k * MAXF + tt] * ct[idx] - Xs[(NBIN + k) * MAXF + tt] * st[idx];
+      const float2 x = Xs[k * MAXF + tt], w = tw[idx];
+      a2 = fmaf(x.x, w.x, a2);
+      a3 = fmaf(x.y, w.y, a3);
       idx += n;
       if (idx >= NFFT) idx -= NFFT;
     }
+    a2 -= a3;
     total += ADJ ? (acc + a2) : (acc + 2.0f * a2);
   }
   return ADJ ? total : total / (float)(NFFT * cnt);
@@ -62,8 +67,8 @@ __device__ __forceinline__ float synth_at(int q, const float* Xs, int t0, const 
 // ADJ = true  : dwave = stft^T(dspec)           (same shape; reflect padding folded back)
 template <bool ADJ>
 __global__ __launch_bounds__(256) void synth_kernel(const float* __restrict__ spec, float* __restrict__ wave) {
-  __shared__ float Xs[2 * NBIN * MAXF];
-  __shared__ float ct[NFFT + 1], st[NFFT + 1];
+  __shared__ float2 Xs[NBIN * MAXF];
+  __shared__ float2 tw[NFFT + 1];
   const int tid = threadIdx.x, b = blockIdx.y, i0 = blockIdx.x * CHUNK;
   const int i1 = min(WLEN, i0 + CHUNK);
   int qlo = i0 + PADL, qhi = i1 - 1 + PADL;
@@ -71,24 +76,27 @@ __global__ __launch_bounds__(256) void synth_kernel(const float* __restrict__ sp
     if (i0 == 0) qlo = 0;
     if (i1 == WLEN) qhi = OLA_LEN - 1;
   }
-  int t0, tdummy;
+  int t0;
   frames_covering(qlo, t0);
   int t1 = qhi / HOP;
   if (t1 > NFRAME - 1) t1 = NFRAME - 1;
   const int nf = t1 - t0 + 1;                            // <= MAXF by construction
-  (void)tdummy;
-  fill_twiddles(ct, st, tid, 256);
+  for (int m = tid; m < NFFT; m += 256) {
+    double sn, cs;
+    sincospi(2.0 * (double)m / (double)NFFT, &sn, &cs);
+    tw[m] = make_float2((float)cs, (float)sn);
+  }
   const float* src = spec + (int64_t)b * 2 * NBIN * NFRAME;
-  for (int idx = tid; idx < 2 * NBIN * MAXF; idx += 256) {
-    const int row = idx / MAXF, tt = idx % MAXF;
-    Xs[idx] = tt < nf ? src[row * NFRAME + t0 + tt] : 0.f;
+  for (int idx = tid; idx < NBIN * MAXF; idx += 256) {
+    const int k = idx / MAXF, tt = idx % MAXF;
+    Xs[idx] = tt < nf ? make_float2(src[k * NFRAME + t0 + tt], src[(NBIN + k) * NFRAME + t0 + tt]) : make_float2(0.f, 0.f);
   }
   __syncthreads();
   for (int i = i0 + tid; i < i1; i += 256) {
-    float v = synth_at<ADJ>(i + PADL, Xs, t0, ct, st);
+    float v = synth_at<ADJ>(i + PADL, Xs, t0, tw);
     if (ADJ) {
-      if (i >= 1 && i <= PADL) v += synth_at<true>(PADL - i, Xs, t0, ct, st);
-      if (i >= WLEN - 1 - PADL && i <= WLEN - 2) v += synth_at<true>(2 * (WLEN - 1) - i + PADL, Xs, t0, ct, st);
+      if (i >= 1 && i <= PADL) v += synth_at<true>(PADL - i, Xs, t0, tw);
+      if (i >= WLEN - 1 - PADL && i <= WLEN - 2) v += synth_at<true>(2 * (WLEN - 1) - i + PADL, Xs, t0, tw);
     }
     wave[(int64_t)b * WLEN + i] = v;
   }
