@@ -21,14 +21,6 @@ constexpr int MAXF = 16;                               // frames staged per synt
 constexpr int TG = 16;                                 // frames per workgroup (analysis)
 constexpr int SPAN = HOP * (TG - 1) + NFFT;            // samples staged per analysis workgroup
 
-__device__ __forceinline__ void fill_twiddles(float* ct, float* st, int tid, int nthreads) {
-  for (int m = tid; m < NFFT; m += nthreads) {
-    double s, c;
-    sincospi(2.0 * (double)m / (double)NFFT, &s, &c);
-    ct[m] = (float)c;
-    st[m] = (float)s;
-  }
-}
 __device__ __forceinline__ int frames_covering(int q, int& tlo) {   // returns count, sets first frame
   int thi = q / HOP;
   if (thi > NFRAME - 1) thi = NFRAME - 1;
@@ -107,9 +99,13 @@ __global__ __launch_bounds__(256) void synth_kernel(const float* __restrict__ sp
 template <bool ADJ>
 __global__ __launch_bounds__(256) void analysis_kernel(const float* __restrict__ wave, float* __restrict__ spec) {
   __shared__ float fs[SPAN];
-  __shared__ float ct[NFFT + 1], st[NFFT + 1];
+  __shared__ float2 tw[NFFT + 1];
   const int tid = threadIdx.x, b = blockIdx.y, tg0 = blockIdx.x * TG;
-  fill_twiddles(ct, st, tid, 256);
+  for (int m = tid; m < NFFT; m += 256) {
+    double sn, cs;
+    sincospi(2.0 * (double)m / (double)NFFT, &sn, &cs);
+    tw[m] = make_float2((float)cs, (float)sn);
+  }
   const float* src = wave + (int64_t)b * WLEN;
   for (int s = tid; s < SPAN; s += 256) {
     const int q = HOP * tg0 + s;                          // OLA / padded coordinate
@@ -133,7 +129,8 @@ __global__ __launch_bounds__(256) void analysis_kernel(const float* __restrict__
   const float* base = fs + HOP * (half * (TG / 2));
   int idx = 0;
   for (int n = 0; n < NFFT; ++n) {
-    const float c = ct[idx], s = st[idx];
+    const float2 w = tw[idx];
+    const float c = w.x, s = w.y;
 #pragma unroll
     for (int f = 0; f < TG / 2; ++f) {
       const float x = base[HOP * f + n];
