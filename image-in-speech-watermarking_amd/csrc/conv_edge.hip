@@ -145,6 +145,138 @@ __global__ __launch_bounds__(256) void conv_fanin_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- weight gradients
+// dw[co][ci][t] = sum_pixels dypre[co][p] * x[ci][p + off_t], db[co] = sum dypre[co][p]  (dypre = dy * act'(y)).
+// The generic kernel gave every thread 5 weight elements and two LDS reads per multiply-add; here a thread owns a
+// (tap, 4-channel) slot so that one 16-byte LDS read feeds 4 or 8 multiply-adds, a workgroup walks `tpb` tiles with
+// the sums in registers, and adds them with one atomic per weight at the end.
+
+// "fan-in" layer (OutputProj): x NHWC [B,H,W,NC], dy / y NCHW [B,2,H,W];  thread = (tap, channel quad), 8 sums
+template <int NC>
+__global__ __launch_bounds__(256) void conv_fanin_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ dy, float* __restrict__ dw,
+                                                            float* __restrict__ db, int B, int H, int W, int act, int tpb) {
+  constexpr int CPP = NC / 4, NCH = 100 * CPP, NL = (NCH + 255) / 256, NSLOT = 9 * CPP;
+  static_assert(NSLOT + 2 <= 256, "one thread per (tap, channel quad) + the two bias sums");
+  __shared__ __attribute__((aligned(16))) float tile[100 * NC];
+  __shared__ float dpre[2][64];
+  const int tid = threadIdx.x, tw = W / 8, ntiles = B * (H / 8) * tw;
+  const int tap = tid / CPP, quad = tid % CPP;
+  float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f}, bsum = 0.f;
+  for (int t = blockIdx.x * tpb; t < min(ntiles, (int)(blockIdx.x + 1) * tpb); ++t) {
+    const int b = t / ((H / 8) * tw), tr = t % ((H / 8) * tw), ty0 = (tr / tw) * 8, tx0 = (tr % tw) * 8;
+    float4 v[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int idx = min(tid + 256 * k, NCH - 1), pix = idx / CPP, part = idx % CPP;
+      const int yy = min(max(ty0 + pix / 10 - 1, 0), H - 1), xx = min(max(tx0 + pix % 10 - 1, 0), W - 1);
+      v[k] = *reinterpret_cast<const float4*>(x + (((int64_t)b * H + yy) * W + xx) * NC + 4 * part);
+    }
+    float dp = 0.f;
+    if (tid < 128) {
+      const int co = tid >> 6, p = tid & 63;
+      const int64_t o = (((int64_t)b * 2 + co) * H + ty0 + (p >> 3)) * W + tx0 + (p & 7);
+      dp = dy[o] * act_grad_out(act ? y[o] : 1.f, act);
+    }
+    __syncthreads();                                          // previous tile fully consumed
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < NCH) {
+        const int pix = idx / CPP;
+        const int yy = ty0 + pix / 10 - 1, xx = tx0 + pix % 10 - 1;
+        *reinterpret_cast<float4*>(tile + idx * 4) = (yy < 0 || yy >= H || xx < 0 || xx >= W) ? make_float4(0.f, 0.f, 0.f, 0.f) : v[k];
+      }
+    }
+    if (tid < 128) dpre[tid >> 6][tid & 63] = dp;
+    __syncthreads();
+    if (tid < NSLOT) {
+      const float* src = tile + ((tap / 3) * 10 + tap % 3) * NC + 4 * quad;
+#pragma unroll 8
+      for (int p = 0; p < 64; ++p) {
+        const float4 xv = *reinterpret_cast<const float4*>(src + ((p >> 3) * 10 + (p & 7)) * NC);
+        const float d0 = dpre[0][p], d1 = dpre[1][p];
+        acc0[0] += d0 * xv.x; acc0[1] += d0 * xv.y; acc0[2] += d0 * xv.z; acc0[3] += d0 * xv.w;
+        acc1[0] += d1 * xv.x; acc1[1] += d1 * xv.y; acc1[2] += d1 * xv.z; acc1[3] += d1 * xv.w;
+      }
+    } else if (tid < NSLOT + 2) {
+      for (int p = 0; p < 64; ++p) bsum += dpre[tid - NSLOT][p];
+    }
+  }
+  if (tid < NSLOT) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      atomicAdd(dw + ((int64_t)0 * NC + 4 * quad + c) * 9 + tap, acc0[c]);
+      atomicAdd(dw + ((int64_t)1 * NC + 4 * quad + c) * 9 + tap, acc1[c]);
+    }
+  } else if (tid < NSLOT + 2 && db) {
+    atomicAdd(db + (tid - NSLOT), bsum);
+  }
+}
+
+// "fan-out" layer (InputProj): x NCHW [B,2,H,W], dy / y NHWC [B,H,W,NO];  thread = (input plane x tap, output quad), 4 sums
+template <int NO>
+__global__ __launch_bounds__(256) void conv_fanout_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ dy, float* __restrict__ dw,
+                                                             float* __restrict__ db, int B, int H, int W, int act, int tpb) {
+  constexpr int NQ = NO / 4, NSLOT = 18 * NQ;                  // 8x8-pixel tiles: x tile [2][10][10], dypre [64][NO]
+  static_assert(NSLOT + NQ <= 256, "one thread per (plane, tap, output quad) + the bias quads");
+  __shared__ float xt[2][10][10];
+  __shared__ __attribute__((aligned(16))) float dpre[64 * NO];
+  const int tid = threadIdx.x, tw = W / 8, ntiles = B * (H / 8) * tw;
+  const int slot = tid / NQ, quad = tid % NQ, s_pl = slot / 9, tap = slot % 9;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int NL = (64 * NQ + 255) / 256;
+  for (int t = blockIdx.x * tpb; t < min(ntiles, (int)(blockIdx.x + 1) * tpb); ++t) {
+    const int b = t / ((H / 8) * tw), tr = t % ((H / 8) * tw), ty0 = (tr / tw) * 8, tx0 = (tr % tw) * 8;
+    float4 g[NL], yv[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int idx = min(tid + 256 * k, 64 * NQ - 1), p = idx / NQ, q4 = idx % NQ;
+      const int64_t o = (((int64_t)b * H + ty0 + (p >> 3)) * W + tx0 + (p & 7)) * NO + 4 * q4;
+      g[k] = *reinterpret_cast<const float4*>(dy + o);
+      yv[k] = act ? *reinterpret_cast<const float4*>(y + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    float xv = 0.f;
+    if (tid < 200) {
+      const int s = tid / 100, r = (tid % 100) / 10, c = tid % 10;
+      const int yy = ty0 + r - 1, xx = tx0 + c - 1;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) xv = x[(((int64_t)b * 2 + s) * H + yy) * W + xx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < 64 * NQ)
+        *reinterpret_cast<float4*>(dpre + idx * 4) = make_float4(g[k].x * act_grad_out(yv[k].x, act), g[k].y * act_grad_out(yv[k].y, act),
+                                                                 g[k].z * act_grad_out(yv[k].z, act), g[k].w * act_grad_out(yv[k].w, act));
+    }
+    if (tid < 200) xt[tid / 100][(tid % 100) / 10][tid % 10] = xv;
+    __syncthreads();
+    if (tid < NSLOT) {
+#pragma unroll 8
+      for (int p = 0; p < 64; ++p) {
+        const float xs = xt[s_pl][(p >> 3) + tap / 3][(p & 7) + tap % 3];
+        const float4 d = *reinterpret_cast<const float4*>(dpre + p * NO + 4 * quad);
+        acc[0] += d.x * xs; acc[1] += d.y * xs; acc[2] += d.z * xs; acc[3] += d.w * xs;
+      }
+    } else if (tid < NSLOT + NQ) {
+      const int q4 = tid - NSLOT;
+      for (int p = 0; p < 64; ++p) {
+        const float4 d = *reinterpret_cast<const float4*>(dpre + p * NO + 4 * q4);
+        acc[0] += d.x; acc[1] += d.y; acc[2] += d.z; acc[3] += d.w;
+      }
+    }
+  }
+  if (tid < NSLOT) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) atomicAdd(dw + ((int64_t)(4 * quad + c) * 2 + s_pl) * 9 + tap, acc[c]);
+  } else if (tid < NSLOT + NQ && db) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) atomicAdd(db + 4 * (tid - NSLOT) + c, acc[c]);
+  }
+}
+
 }  // namespace
 
 // Returns -1 when the layer is not one of the edge shapes (caller uses the generic kernels).
@@ -184,6 +316,26 @@ int wm_conv_edge_dx(const WmConv& c, const float* w, const float* y, const float
     const dim3 grid(c.B * (c.H / 8) * (c.W / 8));
     if (c.Cout == 32) hipLaunchKernelGGL(conv_fanin_kernel<32>, grid, dim3(256), 0, st, dy, gy, w, nullptr, dx, c.H, c.W, 1, 0, c.act, accumulate);
     else hipLaunchKernelGGL(conv_fanin_kernel<64>, grid, dim3(256), 0, st, dy, gy, w, nullptr, dx, c.H, c.W, 1, 0, c.act, accumulate);
+    WM_CHECK_LAUNCH();
+    return WM_OK;
+  }
+  return -1;
+}
+
+int wm_conv_edge_dw(const WmConv& c, const float* x, const float* y, const float* dy, float* dw, float* db, hipStream_t st) {
+  if (c.transposed || c.KH != 3 || c.KW != 3 || c.SH != 1 || c.SW != 1 || c.PH != 1 || c.PW != 1 || (c.H & 7) || (c.W & 7)) return -1;
+  const int ntiles = c.B * (c.H / 8) * (c.W / 8);
+  int tpb = (ntiles + 1023) / 1024;                           // ~1024 workgroups: their atomics per weight stay cheap
+  if (tpb < 1) tpb = 1;
+  const dim3 grid((ntiles + tpb - 1) / tpb);
+  if (c.in_nhwc && !c.out_nhwc && c.Cout == 2 && (c.Cin == 32 || c.Cin == 64)) {
+    if (c.Cin == 32) hipLaunchKernelGGL(conv_fanin_dw_kernel<32>, grid, dim3(256), 0, st, x, y, dy, dw, db, c.B, c.H, c.W, c.act, tpb);
+    else hipLaunchKernelGGL(conv_fanin_dw_kernel<64>, grid, dim3(256), 0, st, x, y, dy, dw, db, c.B, c.H, c.W, c.act, tpb);
+    WM_CHECK_LAUNCH();
+    return WM_OK;
+  }
+  if (!c.in_nhwc && c.out_nhwc && c.Cin == 2 && c.Cout == 32) {
+    hipLaunchKernelGGL(conv_fanout_dw_kernel<32>, grid, dim3(256), 0, st, x, y, dy, dw, db, c.B, c.H, c.W, c.act, tpb);
     WM_CHECK_LAUNCH();
     return WM_OK;
   }

@@ -10,6 +10,7 @@
 int wm_conv_edge_fwd(const WmConv& c, const float* x, const float* w, const float* b, float* y, hipStream_t st);
 int wm_conv_edge_dx(const WmConv& c, const float* w, const float* y, const float* dy, float* dx, int accumulate,
                     hipStream_t st);
+int wm_conv_edge_dw(const WmConv& c, const float* x, const float* y, const float* dy, float* dw, float* db, hipStream_t st);
 
 namespace {
 
@@ -349,6 +350,10 @@ extern "C" int wm_conv_bwd(const WmConv* c, const float* x, const float* w, cons
       hipLaunchKernelGGL(conv_dx_kernel, dim3(grid_for(total)), dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate, total);
       WM_CHECK_LAUNCH();
     }
+  }
+  if (dw) {
+    const int edge = wm_conv_edge_dw(*c, x, y, dy, dw, db, st);
+    if (edge >= 0) return edge;
   }
   const bool tiled = dw && !c->transposed && c->KH == 3 && c->KW == 3 && c->SH == 1 && c->SW == 1 && c->PH == 1 &&
                      c->PW == 1 && (c->H % 8) == 0 && (c->W % 8) == 0 &&
