@@ -292,6 +292,8 @@ class UformerAudio(nn.Module):
         buffer, reused by every layer, grown on demand (before any graph capture: the eager warm-up sizes it)."""
         sc = getattr(self, "_scr", None)
         if sc is None or sc.device != dev or sc.numel() < floats:
+            if sc is not None:                                     # a captured step may still point into the old buffer
+                self.__dict__.setdefault("_scr_retired", []).append(sc)
             sc = self._scr = torch.empty(int(floats), device=dev)
         return sc
 
@@ -306,6 +308,8 @@ class UformerAudio(nn.Module):
         sizes = [(n + 63) // 64 * 64 for n in sizes]
         buf = getattr(self, "_blk_scr", None)
         if buf is None or buf.device != dev or buf.numel() < sum(sizes):
+            if buf is not None:                                    # a captured step may still point into the old buffer
+                self.__dict__.setdefault("_scr_retired", []).append(buf)
             buf = self._blk_scr = torch.empty(sum(sizes), device=dev)
         out, off = [], 0
         for n in sizes:
