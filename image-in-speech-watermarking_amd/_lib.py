@@ -72,6 +72,11 @@ _SIGS = {
     "wm_maxpool_bwd": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_stft256_tiles_per_utterance": [c_i64],
     "wm_stft256_tiles": [c_f, c_i64, c_i32, c_f, c_fl, c_f],
+    "wm_stft255_frames": [c_i64],
+    "wm_stft255_tiles_per_utterance": [c_i64],
+    "wm_stft255_tiles": [c_f, c_i64, c_i32, c_f, c_fl, c_f],
+    "wm_istft255_stitch": [c_f, c_i32, c_i32, c_i32, c_f, c_i64, c_fl, c_f],
+    "wm_wave_attack": [c_f, c_f, c_i64, c_i32, c_i32, c_fl, c_fl, c_u64, c_f, c_f],
     "wm_istft255_fwd": [c_f, c_f, c_i32, c_f],
     "wm_stft255_fwd": [c_f, c_f, c_i32, c_f],
     "wm_istft255_bwd": [c_f, c_f, c_i32, c_f],

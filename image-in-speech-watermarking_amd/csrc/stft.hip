@@ -21,9 +21,9 @@ constexpr int MAXF = 16;                               // frames staged per synt
 constexpr int TG = 16;                                 // frames per workgroup (analysis)
 constexpr int SPAN = HOP * (TG - 1) + NFFT;            // samples staged per analysis workgroup
 
-__device__ __forceinline__ int frames_covering(int q, int& tlo) {   // returns count, sets first frame
+__device__ __forceinline__ int frames_covering(int q, int& tlo, int nframe = NFRAME) {   // returns count, sets first frame
   int thi = q / HOP;
-  if (thi > NFRAME - 1) thi = NFRAME - 1;
+  if (thi > nframe - 1) thi = nframe - 1;
   int lo = q - (NFFT - 1);
   tlo = lo <= 0 ? 0 : (lo + HOP - 1) / HOP;
   return thi - tlo + 1;
@@ -32,9 +32,9 @@ __device__ __forceinline__ int frames_covering(int q, int& tlo) {   // returns c
 // sum over frames covering OLA position q of sum_k w_k (Xr cos - Xi sin).  Twiddles and spectrum values are held as
 // (cos, sin) / (re, im) pairs so that one 8-byte LDS read feeds two multiply-adds (the loop is LDS-issue bound).
 template <bool ADJ>
-__device__ __forceinline__ float synth_at(int q, const float2* Xs, int t0, const float2* tw) {
+__device__ __forceinline__ float synth_at(int q, const float2* Xs, int t0, const float2* tw, int nframe = NFRAME) {
   int tlo;
-  const int cnt = frames_covering(q, tlo);
+  const int cnt = frames_covering(q, tlo, nframe);
   float total = 0.f;
   for (int f = 0; f < cnt; ++f) {
     const int t = tlo + f, n = q - HOP * t, tt = t - t0;
@@ -199,6 +199,148 @@ __global__ __launch_bounds__(256) void stft256_tiles_kernel(const float* __restr
   *reinterpret_cast<float4*>(o + 128 * 128 + 4) = make_float4(im[4], im[5], im[6], im[7]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Whole-utterance pair of the evaluation path (rows N1 / N2): SpeechDataTest.prepare_data (audio_test.py:313-343) and
+// the re-analysis after the attack (:676-688) are torch.stft(n_fft=255) of a waveform of any length cut into
+// [2,128,128] tiles; reconstruct_audio (:594-600) concatenates the encoded tiles along the frame axis (the last one
+// trimmed to len_last_clip frames) and calls torch.istft(n_fft=255, length=L).  Same direct real DFT as above with
+// the frame count and the waveform length as run-time values; frame t lives in tile t / 128, column t % 128.
+__global__ __launch_bounds__(256) void istft255_stitch_kernel(const float* __restrict__ tiles, float* __restrict__ wave,
+                                                             int n_tiles, int nframe, int64_t L, float out_scale) {
+  __shared__ float2 Xs[NBIN * MAXF];
+  __shared__ float2 tw[NFFT + 1];
+  const int tid = threadIdx.x, u = blockIdx.y;
+  const int64_t i0 = (int64_t)blockIdx.x * CHUNK, i1 = i0 + CHUNK < L ? i0 + CHUNK : L;
+  const int64_t ola = NFFT + (int64_t)HOP * (nframe - 1);      // torch pads with zeros beyond the overlap-add length
+  float* dst = wave + (int64_t)u * L;
+  if (nframe <= 0 || i0 + PADL >= ola) {
+    for (int64_t i = i0 + tid; i < i1; i += 256) dst[i] = 0.f;
+    return;
+  }
+  const int qlo = (int)i0 + PADL;
+  int qhi = (int)(i1 - 1) + PADL;
+  if (qhi > ola - 1) qhi = (int)(ola - 1);
+  int t0;
+  frames_covering(qlo, t0, nframe);
+  int t1 = qhi / HOP;
+  if (t1 > nframe - 1) t1 = nframe - 1;
+  const int nf = t1 - t0 + 1;                                  // <= MAXF: (CHUNK + NFFT - 1) / HOP + 1 = 14
+  for (int m = tid; m < NFFT; m += 256) {
+    double sn, cs;
+    sincospi(2.0 * (double)m / (double)NFFT, &sn, &cs);
+    tw[m] = make_float2((float)cs, (float)sn);
+  }
+  const float* src = tiles + (int64_t)u * n_tiles * 2 * NBIN * 128;
+  for (int idx = tid; idx < NBIN * MAXF; idx += 256) {
+    const int k = idx / MAXF, tt = idx % MAXF, t = t0 + tt;
+    float2 v = make_float2(0.f, 0.f);
+    if (tt < nf) {
+      const float* p = src + ((int64_t)(t >> 7) * 2 * NBIN + k) * 128 + (t & 127);
+      v = make_float2(p[0], p[NBIN * 128]);
+    }
+    Xs[idx] = v;
+  }
+  __syncthreads();
+  for (int64_t i = i0 + tid; i < i1; i += 256)
+    dst[i] = i + PADL < ola ? synth_at<false>((int)i + PADL, Xs, t0, tw, nframe) * out_scale : 0.f;
+}
+
+__global__ __launch_bounds__(256) void stft255_tiles_kernel(const float* __restrict__ wave, float* __restrict__ tiles,
+                                                            int64_t L, int nframe, int tiles_per_utt, float scale) {
+  __shared__ float fs[SPAN];
+  __shared__ float2 tw[NFFT + 1];
+  const int tid = threadIdx.x;
+  const int groups = tiles_per_utt * (128 / TG);
+  const int u = blockIdx.x / groups, tg0 = (blockIdx.x % groups) * TG;
+  for (int m = tid; m < NFFT; m += 256) {
+    double sn, cs;
+    sincospi(2.0 * (double)m / (double)NFFT, &sn, &cs);
+    tw[m] = make_float2((float)cs, (float)sn);
+  }
+  const float* src = wave + (int64_t)u * L;
+  for (int s = tid; s < SPAN; s += 256) {
+    int64_t i = (int64_t)HOP * tg0 + s - PADL;
+    if (i < 0) i = -i;                                         // reflect, PADL < L
+    if (i >= L) i = 2 * (L - 1) - i;
+    fs[s] = (i >= 0 && i < L) ? src[i] : 0.f;                  // frames past the utterance are zeroed below anyway
+  }
+  __syncthreads();
+  const int k = tid & (NBIN - 1), half = tid >> 7;
+  float re[TG / 2], im[TG / 2];
+#pragma unroll
+  for (int f = 0; f < TG / 2; ++f) { re[f] = 0.f; im[f] = 0.f; }
+  const float* base = fs + HOP * (half * (TG / 2));
+  int idx = 0;
+  for (int n = 0; n < NFFT; ++n) {
+    const float2 w = tw[idx];
+#pragma unroll
+    for (int f = 0; f < TG / 2; ++f) {
+      const float x = base[HOP * f + n];
+      re[f] += x * w.x;
+      im[f] -= x * w.y;
+    }
+    idx += k;
+    if (idx >= NFFT) idx -= NFFT;
+  }
+  const int f0 = tg0 + half * (TG / 2), tile = f0 >> 7;
+  float* dst = tiles + (((int64_t)(u * tiles_per_utt + tile) * 2) * NBIN + k) * 128 + (f0 & 127);
+#pragma unroll
+  for (int f = 0; f < TG / 2; ++f) {
+    const bool live = f0 + f < nframe;
+    dst[f] = live ? re[f] * scale : 0.f;
+    dst[NBIN * 128 + f] = live ? im[f] * scale : 0.f;
+  }
+}
+
+// Whole-utterance waveform attacks of the evaluation loop that need no filter state (audio_attack.py:55-58 amplitude
+// scaling; awgn :99-125 with the noise drawn from Philox instead of numpy's generator): power pass + apply pass.
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+  const float m = sqrtf(-2.0f * logf(u01(a)));
+  float sn, cs;
+  sincospif(2.0f * u01(b), &sn, &cs);
+  z0 = m * cs;
+  z1 = m * sn;
+}
+// one workgroup per utterance, fixed summation order: the noise level (and so the attacked waveform) is reproducible
+__global__ __launch_bounds__(1024) void wave_power_kernel(const float* __restrict__ wave, float* __restrict__ power, int64_t L) {
+  __shared__ float red[16];
+  const float* w = wave + (int64_t)blockIdx.x * L;
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < L; i += 1024) s += w[i] * w[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    power[blockIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(256) void wave_attack_kernel(const float* __restrict__ wave, float* __restrict__ out,
+                                                          const float* __restrict__ power, int64_t L, int flags, float snr_db,
+                                                          float amp, uint64_t seed) {
+  const int u = blockIdx.y;
+  float sigma = 0.f;
+  if (flags & 2) sigma = sqrtf(power[u] / (float)L * exp10f(-snr_db / 10.0f));
+  const float a = (flags & 8) ? amp : 1.0f;
+  const float* w = wave + (int64_t)u * L;
+  float* o = out + (int64_t)u * L;
+  for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 * 4 < L; i4 += (int64_t)gridDim.x * 256) {
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (flags & 2) {
+      uint32_t r[4];
+      philox4x32((uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)u, 0x57a7u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+      box_muller(r[0], r[1], z[0], z[1]);
+      box_muller(r[2], r[3], z[2], z[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t i = i4 * 4 + q;
+      if (i < L) o[i] = (w[i] + sigma * z[q]) * a;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int32_t wm_stft256_tiles_per_utterance(int64_t L) {
@@ -240,6 +382,46 @@ extern "C" int wm_istft255_bwd(const float* dwave, float* dspec, int32_t B, void
   if (!dwave || !dspec || B <= 0) return WM_EINVAL;
   hipLaunchKernelGGL(analysis_kernel<true>, dim3(NFRAME / TG, B), dim3(256), 0, static_cast<hipStream_t>(stream),
                      dwave, dspec);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int32_t wm_stft255_tiles_per_utterance(int64_t L) {
+  const int64_t frames = 1 + (L - 1) / HOP;                   // centre padding adds 2 * 127 = n_fft - 1 samples
+  return (int32_t)(frames / 128 + 1);                         // len_pad = 128 - frames % 128 (audio_test.py:318-319)
+}
+extern "C" int32_t wm_stft255_frames(int64_t L) { return (int32_t)(1 + (L - 1) / HOP); }
+
+extern "C" int wm_stft255_tiles(const float* wave, int64_t L, int32_t U, float* tiles, float scale, void* stream) {
+  if (!wave || !tiles || U <= 0 || L <= PADL || L > (int64_t)1 << 30) return WM_EINVAL;
+  const int nframe = wm_stft255_frames(L), tpu = wm_stft255_tiles_per_utterance(L);
+  hipLaunchKernelGGL(stft255_tiles_kernel, dim3(U * tpu * (128 / TG)), dim3(256), 0, static_cast<hipStream_t>(stream), wave,
+                     tiles, L, nframe, tpu, scale);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int wm_istft255_stitch(const float* tiles, int32_t n_tiles, int32_t last_len, int32_t U, float* wave, int64_t L,
+                                  float out_scale, void* stream) {
+  if (!tiles || !wave || n_tiles <= 0 || last_len < 0 || last_len > 128 || U <= 0 || L <= 0 || L > (int64_t)1 << 30)
+    return WM_EINVAL;
+  const int nframe = (n_tiles - 1) * 128 + last_len;
+  hipLaunchKernelGGL(istft255_stitch_kernel, dim3((unsigned)((L + CHUNK - 1) / CHUNK), U), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), tiles, wave, n_tiles, nframe, L, out_scale);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int wm_wave_attack(const float* wave, float* out, int64_t L, int32_t U, int32_t flags, float snr_db, float amp,
+                              uint64_t seed, float* power /* [U] scratch */, void* stream) {
+  if (!wave || !out || L <= 0 || U <= 0 || (flags & ~10) || ((flags & 2) && !power)) return WM_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned gx = (unsigned)((L + 4095) / 4096 > 256 ? 256 : (L + 4095) / 4096);
+  if (flags & 2) {
+    hipLaunchKernelGGL(wave_power_kernel, dim3(U), dim3(1024), 0, st, wave, power, L);
+    WM_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(wave_attack_kernel, dim3(gx, U), dim3(256), 0, st, wave, out, power, L, flags, snr_db, amp, seed);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

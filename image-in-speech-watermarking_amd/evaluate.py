@@ -1,0 +1,109 @@
+"""Whole-utterance evaluation path on the device: the ``data_mode='stft'`` branch of the
+reference's ``SpeechDataTest.prepare_data`` (audio_test.py:299-343) and ``reconstruct_audio`` (audio_test.py:528-785).
+
+Same call surface and return tuple as the reference; what changes is where the work runs:
+
+* the utterance is analysed (``wm_stft255_tiles``), stitched back (``wm_istft255_stitch``) and re-analysed after the
+  attack by HIP kernels, the waveform never leaves HBM (the reference round-trips every tile through numpy);
+* the tiles of an utterance go through the model as one batch (the reference calls it tile by tile);
+* the attacks that run here are the state-free ones (``closed_loop``, ``amplitude_scaling-f``, ``awgn-snr``); the
+  filter / codec attacks of audio_attack.py (scipy, librosa, ffmpeg) are CPU tools outside the hot path and raise.
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+def prepare_utterance(wave, audio_scale="0"):
+    """One entry of SpeechDataTest.prepare_data: ``[wave, clips, len_last_clip]`` with clips ``[n, 2, 128, 128]``.
+
+    ``audio_scale``: the reference's string option; a plain number of more than one character scales the tiles
+    (audio_test.py:327-330), '0' leaves them alone; the 'min-max' range form needs dataset-wide statistics the path
+    does not hold and is rejected."""
+    if "-" in audio_scale:
+        raise ValueError("range-style audio_scale needs dataset statistics (audio_test.py:331-337): not on this path")
+    if wave.dim() == 1:
+        wave = wave[None]
+    if wave.dim() != 2 or wave.shape[0] != 1 or not wave.is_cuda:
+        raise ValueError("prepare_utterance takes one CUDA waveform [1, L]")
+    scale = float(audio_scale) if len(audio_scale) > 1 else 1.0
+    clips, frames = ops.stft255_tiles(wave.contiguous().float(), scale)
+    return [wave, clips, frames % 128]
+
+
+def signaltonoise(a):
+    """audio_test.py:522-526: 20 log10 |mean / std| (population std); 0-std input gives -inf as numpy's log10(0)."""
+    a = a.reshape(-1).double()
+    sd = a.std(unbiased=False)
+    m = a.mean()
+    r = torch.where(sd == 0, torch.zeros_like(m), m / sd).abs()
+    return 20.0 * math.log10(r.item()) if r.item() > 0 else float("-inf")
+
+
+def _mse(a, b):
+    loss = torch.zeros((), device=a.device)
+    ops.mse_fwd_bwd(a.contiguous().float(), b.contiguous().float(), loss)
+    return loss.item()
+
+
+def _attack(wave, attack, seed):
+    name, _, param = (attack or "closed_loop").partition("-")
+    if name in ("closed_loop", "no", ""):
+        return wave
+    if name == "amplitude_scaling":
+        return ops.wave_attack(wave, amp=float(param) if param else 0.8)
+    if name == "awgn":
+        return ops.wave_attack(wave, snr_db=float(param), seed=seed)
+    raise NotImplementedError(f"attack '{name}' is a CPU tool of audio_attack.py outside the MI355X path (DESIGN.md, out of scope)")
+
+
+@torch.no_grad()
+def reconstruct_audio(audio_data, watermark, model, n_fft=255, attack=None, data_mode="stft", audio_scale="0",
+                      data_min=None, data_max=None, model_name="uformer", batch=32, seed=0):
+    """reconstruct_audio of audio_test.py:528-785 for ``data_mode='stft'``.
+
+    Returns ``(audio_att, recon_audio, watermark, wms_decode, wms_att_decode, mse_loss, wm_loss, wm_loss_att,
+    snr_ori, snr_recon)``: tensors stay on the device, the per-tile lists hold ``[1, 1, 32, 32]`` tensors."""
+    if data_mode != "stft" or n_fft != 255:
+        raise ValueError("the MI355X evaluation path covers data_mode='stft' with n_fft=255 (audio_test.py:594-600)")
+    if "-" in audio_scale:
+        raise ValueError("range-style audio_scale needs dataset statistics: not on this path")
+    wave, clips, len_last_clip = audio_data[0], audio_data[1], int(audio_data[2])
+    if wave.dim() == 1:
+        wave = wave[None]
+    n = clips.shape[0]
+    L = wave.shape[-1]
+    msg = watermark.reshape(1, 1, 32, 32).float()
+    enc, dec = [], []
+    for i in range(0, n, batch):                                          # audio_test.py:547-556, batched over tiles
+        c = clips[i:i + batch].contiguous()
+        m = msg.expand(c.shape[0], 1, 32, 32).contiguous()
+        if model_name == "uformer":
+            audio_clip, _, _, wm_decode = model(c, m)
+        elif model_name == "modelA":
+            audio_clip, wm_decode = model(c, m)
+        else:
+            raise ValueError(f"unknown model_name '{model_name}'")
+        enc.append(audio_clip)
+        dec.append(wm_decode)
+    enc, dec = torch.cat(enc).contiguous(), torch.cat(dec)
+    factor = 1.0 / float(audio_scale) if len(audio_scale) > 1 else 1.0    # :559-563
+    recon_audio = ops.istft255_stitch(enc, n, len_last_clip, L, factor)   # :594-600
+    mse_loss = _mse(wave.reshape(1, L), recon_audio)                      # :618
+    wm_loss = _mse(msg, dec[n - 1:n])                                     # :625 (the reference keeps the last tile's)
+    audio_att = _attack(recon_audio, attack, seed)                        # :628-660
+    scale = float(audio_scale) if len(audio_scale) > 1 else 1.0
+    att_clips, _ = ops.stft255_tiles(audio_att.contiguous(), scale)       # :676-700
+    dec_att = []
+    for i in range(0, att_clips.shape[0], batch):
+        c = att_clips[i:i + batch].contiguous()
+        dec_att.append(model.wm_decode(c) if model_name == "uformer" else model.decode(c))
+    dec_att = torch.cat(dec_att)
+    wm_losses_att = [_mse(msg, dec_att[j:j + 1]) for j in range(dec_att.shape[0])]   # :706
+    snr_ori = signaltonoise(wave)
+    snr_recon = signaltonoise(recon_audio)
+    return (audio_att.reshape(-1), recon_audio.reshape(-1), watermark, [dec[j:j + 1] for j in range(n)],
+            [dec_att[j:j + 1] for j in range(dec_att.shape[0])], mse_loss, wm_loss,
+            sum(wm_losses_att) / len(wm_losses_att), snr_ori, snr_recon)

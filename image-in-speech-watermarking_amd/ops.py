@@ -194,6 +194,44 @@ def stft256_tiles(wave, scale=1.0):
     return tiles
 
 
+def stft255_tiles(wave, scale=1.0):
+    """torch.stft(n_fft=255) of U equal-length utterances [U, L] cut into tiles (SpeechDataTest.prepare_data):
+    -> ([U * tiles_per_utterance, 2, 128, 128], frames per utterance)."""
+    if wave.dim() != 2 or wave.dtype != torch.float32 or not wave.is_contiguous():
+        raise ValueError("stft255_tiles takes a contiguous float32 [U, L] waveform batch")
+    U, L = wave.shape
+    tpu = lib.wm_stft255_tiles_per_utterance(L)
+    tiles = torch.empty(U * tpu, 2, 128, 128, device=wave.device)
+    check(lib.wm_stft255_tiles(ptr(wave), L, U, ptr(tiles), float(scale), _stream()), "wm_stft255_tiles")
+    return tiles, lib.wm_stft255_frames(L)
+
+
+def istft255_stitch(tiles, n_tiles, last_len, L, out_scale=1.0):
+    """torch.istft(n_fft=255, length=L) of each utterance's n_tiles tiles joined along the frame axis, the last tile
+    trimmed to last_len frames (reconstruct_audio): [U * n_tiles, 2, 128, 128] -> [U, L]."""
+    if tiles.dim() != 4 or tuple(tiles.shape[1:]) != (2, 128, 128) or tiles.dtype != torch.float32 or \
+            not tiles.is_contiguous() or tiles.shape[0] % n_tiles:
+        raise ValueError("istft255_stitch takes contiguous float32 [U * n_tiles, 2, 128, 128] tiles")
+    U = tiles.shape[0] // n_tiles
+    wave = torch.empty(U, L, device=tiles.device)
+    check(lib.wm_istft255_stitch(ptr(tiles), n_tiles, last_len, U, ptr(wave), L, float(out_scale), _stream()),
+          "wm_istft255_stitch")
+    return wave
+
+
+def wave_attack(wave, snr_db=None, amp=None, seed=0):
+    """Whole-utterance AWGN (snr_db) and / or amplitude scaling of [U, L] waveforms."""
+    if wave.dim() != 2 or wave.dtype != torch.float32 or not wave.is_contiguous():
+        raise ValueError("wave_attack takes a contiguous float32 [U, L] waveform batch")
+    U, L = wave.shape
+    out = torch.empty_like(wave)
+    power = torch.empty(U, device=wave.device)
+    flags = (2 if snr_db is not None else 0) | (8 if amp is not None else 0)
+    check(lib.wm_wave_attack(ptr(wave), ptr(out), L, U, flags, float(snr_db or 0.0), float(1.0 if amp is None else amp),
+                             int(seed), ptr(power), _stream()), "wm_wave_attack")
+    return out
+
+
 def istft_fwd(spec, wave, B):
     check(lib.wm_istft255_fwd(ptr(spec), ptr(wave), B, _stream()), "wm_istft255_fwd")
 

@@ -151,6 +151,24 @@ int wm_maxpool_bwd(const float* x, const float* dy, float* dx, int32_t planes, i
 int32_t wm_stft256_tiles_per_utterance(int64_t L);
 int wm_stft256_tiles(const float* wave, int64_t L, int32_t U, float* tiles, float scale, void* stream);
 
+/* ---- whole-utterance STFT pair of the evaluation path.
+ * wm_stft255_tiles: SpeechDataTest.prepare_data (audio_test.py:313-343) and the re-analysis after the attack
+ *   (:676-688): torch.stft(n_fft=255) (hop 63, rectangular, centre / reflect) of U utterances of L samples,
+ *   wm_stft255_frames(L) = 1 + (L - 1) / 63 frames zero-padded to wm_stft255_tiles_per_utterance(L) tiles, times `scale`.
+ *   wave: [U, L], tiles: [U * tiles_per_utterance, 2, 128, 128].  len_last_clip of the reference = frames % 128.
+ * wm_istft255_stitch: reconstruct_audio (audio_test.py:594-600): the n_tiles tiles of an utterance concatenated along
+ *   the frame axis, the last one trimmed to last_len frames, torch.istft(n_fft=255, length=L) (zero beyond the
+ *   overlap-add length), times `out_scale` (the 1 / audio_scale factor of :561-563).  wave: [U, L].
+ * wm_wave_attack: the state-free waveform attacks of the evaluation loop on whole utterances: flags bit1 AWGN at
+ *   snr_db (audio_attack.py:99-125; Philox noise), bit3 amplitude scaling (:55-58).  power: [U] floats scratch. */
+int32_t wm_stft255_frames(int64_t L);
+int32_t wm_stft255_tiles_per_utterance(int64_t L);
+int wm_stft255_tiles(const float* wave, int64_t L, int32_t U, float* tiles, float scale, void* stream);
+int wm_istft255_stitch(const float* tiles, int32_t n_tiles, int32_t last_len, int32_t U, float* wave, int64_t L,
+                       float out_scale, void* stream);
+int wm_wave_attack(const float* wave, float* out, int64_t L, int32_t U, int32_t flags, float snr_db, float amp,
+                   uint64_t seed, float* power, void* stream);
+
 /* ---- in-graph STFT round trip — torch.istft / torch.stft with n_fft=255, hop 63, rectangular
  * window, center/reflect (model.py:2458,2463).  spec: [B,2,128,128] (re|im planes), wave: [B,8002] */
 int wm_istft255_fwd(const float* spec, float* wave, int32_t B, void* stream);

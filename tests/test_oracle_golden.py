@@ -130,3 +130,20 @@ def test_g6_hidden_decoder_and_ber(golden):
     close(mid[:, :, :8, :8], g["mid"], atol=1e-5)
     bits = synth_bits("g6_bits", (4, 1, 32, 32))
     assert abs(O.ber(dec, bits).item() - float(g["ber"])) < 1e-7
+
+
+def test_eval_path_restatement_round_trip_and_tiling():
+    """oracle/eval_path.py (audio_test.py:299-343, 594-600): tile count / len_last_clip rules and the exact round trip of
+    the rectangular-window STFT pair that pins the stitch against the analysis."""
+    from oracle import eval_path as E
+    from synth import chirp_wave
+    for L, tiles, last in ((1000, 1, 16), (8010, 2, 0), (8064, 2, 0), (8065, 2, 1), (12000, 2, 63), (30000, 4, 93)):
+        wave = torch.as_tensor(chirp_wave(L, f"ep{L}"), dtype=torch.float32)
+        w, clips, len_last = E.prepare_utterance(wave)
+        assert clips.shape == (tiles, 2, 128, 128) and len_last == last == (1 + (L - 1) // 63) % 128
+        assert torch.count_nonzero(clips[-1][:, :, len_last:]) == 0
+        back = E.stitch_istft(clips, len_last, L)
+        assert torch.allclose(back, wave, atol=2e-6)
+    short = E.stitch_istft(clips[:1], 10, 2000)                    # length beyond the overlap-add: zero padded
+    assert torch.count_nonzero(short[255 + 63 * 9 - 127:]) == 0
+    assert abs(E.signaltonoise(np.array([1.0, 2.0, 3.0])) - 20 * np.log10(2 / np.sqrt(2 / 3))) < 1e-12
