@@ -43,6 +43,11 @@ class WmAttack(C.Structure):
                 ("rs_h", c_f), ("rs_n", c_i32), ("seed", c_u64), ("step", c_f)]
 
 
+class WmWaveAttack(C.Structure):
+    _fields_ = [("flags", c_i32), ("snr_db", c_fl), ("amp", c_fl), ("echo_gain", c_fl), ("echo_delay", c_i64),
+                ("jitter_count", c_i32), ("reserved", c_i32), ("seed", c_u64)]
+
+
 _SIGS = {
     "wm_abi_version": [],
     "wm_gemm_scratch_floats": [],
@@ -76,7 +81,7 @@ _SIGS = {
     "wm_stft255_tiles_per_utterance": [c_i64],
     "wm_stft255_tiles": [c_f, c_i64, c_i32, c_f, c_fl, c_f],
     "wm_istft255_stitch": [c_f, c_i32, c_i32, c_i32, c_f, c_i64, c_fl, c_f],
-    "wm_wave_attack": [c_f, c_f, c_i64, c_i32, c_i32, c_fl, c_fl, c_u64, c_f, c_f],
+    "wm_wave_attack": [C.POINTER(WmWaveAttack), c_f, c_f, c_i64, c_i32, c_f, c_f],
     "wm_istft255_fwd": [c_f, c_f, c_i32, c_f],
     "wm_stft255_fwd": [c_f, c_f, c_i32, c_f],
     "wm_istft255_bwd": [c_f, c_f, c_i32, c_f],

@@ -317,28 +317,40 @@ __global__ __launch_bounds__(1024) void wave_power_kernel(const float* __restric
   }
 }
 __global__ __launch_bounds__(256) void wave_attack_kernel(const float* __restrict__ wave, float* __restrict__ out,
-                                                          const float* __restrict__ power, int64_t L, int flags, float snr_db,
-                                                          float amp, uint64_t seed) {
-  const int u = blockIdx.y;
+                                                          const float* __restrict__ power, int64_t L, const WmWaveAttack a) {
+  const int u = blockIdx.y, flags = a.flags;
   float sigma = 0.f;
-  if (flags & 2) sigma = sqrtf(power[u] / (float)L * exp10f(-snr_db / 10.0f));
-  const float a = (flags & 8) ? amp : 1.0f;
+  if (flags & 2) sigma = sqrtf(power[u] / (float)L * exp10f(-a.snr_db / 10.0f));
+  const float amp = (flags & 8) ? a.amp : 1.0f;
   const float* w = wave + (int64_t)u * L;
   float* o = out + (int64_t)u * L;
   for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 * 4 < L; i4 += (int64_t)gridDim.x * 256) {
     float z[4] = {0.f, 0.f, 0.f, 0.f};
     if (flags & 2) {
       uint32_t r[4];
-      philox4x32((uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)u, 0x57a7u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+      philox4x32((uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)u, 0x57a7u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
       box_muller(r[0], r[1], z[0], z[1]);
       box_muller(r[2], r[3], z[2], z[3]);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int64_t i = i4 * 4 + q;
-      if (i < L) o[i] = (w[i] + sigma * z[q]) * a;
+      if (i >= L) continue;
+      float v = (w[i] + sigma * z[q]) * amp;
+      if ((flags & 16) && i >= a.echo_delay) v += a.echo_gain * w[i - a.echo_delay];       // audio_attack.py:33-52
+      if (flags & 64) v = rintf(fminf(fmaxf(v, -1.0f), 1.0f) * 127.0f) * (1.0f / 128.0f);   // PCM_U8 write / read (:85-96)
+      o[i] = v;
     }
   }
+}
+// jittering_2 (audio_attack.py:176-193): `count` uniformly drawn sample positions are set to zero
+__global__ void wave_jitter_kernel(float* __restrict__ out, int64_t L, int count, uint64_t seed) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, u = blockIdx.y;
+  if (j >= count) return;
+  uint32_t r[4];
+  philox4x32((uint32_t)j, 0u, (uint32_t)u, 0x6a17u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const int64_t idx = (int64_t)(((uint64_t)r[0] * (uint64_t)L) >> 32);
+  out[(int64_t)u * L + idx] = 0.f;
 }
 
 }  // namespace
@@ -412,16 +424,23 @@ extern "C" int wm_istft255_stitch(const float* tiles, int32_t n_tiles, int32_t l
   return WM_OK;
 }
 
-extern "C" int wm_wave_attack(const float* wave, float* out, int64_t L, int32_t U, int32_t flags, float snr_db, float amp,
-                              uint64_t seed, float* power /* [U] scratch */, void* stream) {
-  if (!wave || !out || L <= 0 || U <= 0 || (flags & ~10) || ((flags & 2) && !power)) return WM_EINVAL;
+extern "C" int wm_wave_attack(const WmWaveAttack* a, const float* wave, float* out, int64_t L, int32_t U, float* power,
+                              void* stream) {
+  if (!a || !wave || !out || L <= 0 || L > (int64_t)1 << 31 || U <= 0 || (a->flags & ~(2 | 8 | 16 | 32 | 64)) ||
+      ((a->flags & 2) && !power) || ((a->flags & 16) && a->echo_delay <= 0) || ((a->flags & 32) && a->jitter_count < 0))
+    return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned gx = (unsigned)((L + 4095) / 4096 > 256 ? 256 : (L + 4095) / 4096);
-  if (flags & 2) {
+  if (a->flags & 2) {
     hipLaunchKernelGGL(wave_power_kernel, dim3(U), dim3(1024), 0, st, wave, power, L);
     WM_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(wave_attack_kernel, dim3(gx, U), dim3(256), 0, st, wave, out, power, L, flags, snr_db, amp, seed);
+  hipLaunchKernelGGL(wave_attack_kernel, dim3(gx, U), dim3(256), 0, st, wave, out, power, L, *a);
   WM_CHECK_LAUNCH();
+  if ((a->flags & 32) && a->jitter_count > 0) {
+    hipLaunchKernelGGL(wave_jitter_kernel, dim3((a->jitter_count + 255) / 256, U), dim3(256), 0, st, out, L, a->jitter_count,
+                       a->seed);
+    WM_CHECK_LAUNCH();
+  }
   return WM_OK;
 }

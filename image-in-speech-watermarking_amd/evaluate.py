@@ -6,8 +6,9 @@ Same call surface and return tuple as the reference; what changes is where the w
 * the utterance is analysed (``wm_stft255_tiles``), stitched back (``wm_istft255_stitch``) and re-analysed after the
   attack by HIP kernels, the waveform never leaves HBM (the reference round-trips every tile through numpy);
 * the tiles of an utterance go through the model as one batch (the reference calls it tile by tile);
-* the attacks that run here are the state-free ones (``closed_loop``, ``amplitude_scaling-f``, ``awgn-snr``); the
-  filter / codec attacks of audio_attack.py (scipy, librosa, ffmpeg) are CPU tools outside the hot path and raise.
+* the attacks that run here are the state-free ones (``closed_loop``, ``amplitude_scaling-f``, ``awgn-snr``,
+  ``echo_addition``, ``jittering_2-n``, ``requantization``); the filter / codec / stretch attacks of audio_attack.py
+  (scipy, librosa, ffmpeg) are CPU tools outside the hot path and raise.
 """
 import math
 
@@ -42,10 +43,11 @@ def signaltonoise(a):
     return 20.0 * math.log10(r.item()) if r.item() > 0 else float("-inf")
 
 
-def _mse(a, b):
-    loss = torch.zeros((), device=a.device)
+def _mse(a, b, out=None):
+    """mean((a - b)^2) into a device scalar (no host synchronisation here)."""
+    loss = torch.zeros((), device=a.device) if out is None else out
     ops.mse_fwd_bwd(a.contiguous().float(), b.contiguous().float(), loss)
-    return loss.item()
+    return loss
 
 
 def _attack(wave, attack, seed):
@@ -56,6 +58,12 @@ def _attack(wave, attack, seed):
         return ops.wave_attack(wave, amp=float(param) if param else 0.8)
     if name == "awgn":
         return ops.wave_attack(wave, snr_db=float(param), seed=seed)
+    if name == "echo_addition":                                           # audio_attack.py:33-52: td = 0.5 s, AA = 0.2
+        return ops.wave_attack(wave, echo=(8000, 0.2))
+    if name == "jittering_2":                                             # :176-193, audio_test.py:652
+        return ops.wave_attack(wave, jitter=int(param) if param else 1000, seed=seed)
+    if name == "requantization":                                          # :85-96 (PCM_U8 round trip)
+        return ops.wave_attack(wave, requantize=True)
     raise NotImplementedError(f"attack '{name}' is a CPU tool of audio_attack.py outside the MI355X path (DESIGN.md, out of scope)")
 
 
@@ -101,9 +109,11 @@ def reconstruct_audio(audio_data, watermark, model, n_fft=255, attack=None, data
         c = att_clips[i:i + batch].contiguous()
         dec_att.append(model.wm_decode(c) if model_name == "uformer" else model.decode(c))
     dec_att = torch.cat(dec_att)
-    wm_losses_att = [_mse(msg, dec_att[j:j + 1]) for j in range(dec_att.shape[0])]   # :706
+    losses_att = torch.zeros(dec_att.shape[0], device=wave.device)        # :706, one host read for all tiles
+    for j in range(dec_att.shape[0]):
+        _mse(msg, dec_att[j:j + 1], losses_att[j])
+    scalars = torch.stack([mse_loss, wm_loss, losses_att.mean()]).tolist()
     snr_ori = signaltonoise(wave)
     snr_recon = signaltonoise(recon_audio)
     return (audio_att.reshape(-1), recon_audio.reshape(-1), watermark, [dec[j:j + 1] for j in range(n)],
-            [dec_att[j:j + 1] for j in range(dec_att.shape[0])], mse_loss, wm_loss,
-            sum(wm_losses_att) / len(wm_losses_att), snr_ori, snr_recon)
+            [dec_att[j:j + 1] for j in range(dec_att.shape[0])], scalars[0], scalars[1], scalars[2], snr_ori, snr_recon)

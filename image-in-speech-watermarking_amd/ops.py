@@ -8,7 +8,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, check, ptr, WmGemm, WmConv, WmAttack, WmReduceJob
+from ._lib import lib, check, ptr, WmGemm, WmConv, WmAttack, WmReduceJob, WmWaveAttack
 
 MODE_FP32, MODE_BF16 = 0, 1
 
@@ -219,16 +219,20 @@ def istft255_stitch(tiles, n_tiles, last_len, L, out_scale=1.0):
     return wave
 
 
-def wave_attack(wave, snr_db=None, amp=None, seed=0):
-    """Whole-utterance AWGN (snr_db) and / or amplitude scaling of [U, L] waveforms."""
+def wave_attack(wave, snr_db=None, amp=None, echo=None, jitter=None, requantize=False, seed=0):
+    """Whole-utterance state-free attacks on [U, L] waveforms: AWGN (snr_db), amplitude scaling (amp), echo addition
+    (echo = (delay_samples, gain)), jittering_2 (jitter = number of zeroed samples), 8-bit requantisation."""
     if wave.dim() != 2 or wave.dtype != torch.float32 or not wave.is_contiguous():
         raise ValueError("wave_attack takes a contiguous float32 [U, L] waveform batch")
     U, L = wave.shape
     out = torch.empty_like(wave)
     power = torch.empty(U, device=wave.device)
-    flags = (2 if snr_db is not None else 0) | (8 if amp is not None else 0)
-    check(lib.wm_wave_attack(ptr(wave), ptr(out), L, U, flags, float(snr_db or 0.0), float(1.0 if amp is None else amp),
-                             int(seed), ptr(power), _stream()), "wm_wave_attack")
+    flags = (2 if snr_db is not None else 0) | (8 if amp is not None else 0) | (16 if echo is not None else 0) | \
+            (32 if jitter is not None else 0) | (64 if requantize else 0)
+    delay, gain = echo if echo is not None else (0, 0.0)
+    a = WmWaveAttack(flags, float(snr_db or 0.0), float(1.0 if amp is None else amp), float(gain), int(delay),
+                     int(jitter or 0), 0, int(seed))
+    check(lib.wm_wave_attack(C.byref(a), ptr(wave), ptr(out), L, U, ptr(power), _stream()), "wm_wave_attack")
     return out
 
 

@@ -159,15 +159,21 @@ int wm_stft256_tiles(const float* wave, int64_t L, int32_t U, float* tiles, floa
  * wm_istft255_stitch: reconstruct_audio (audio_test.py:594-600): the n_tiles tiles of an utterance concatenated along
  *   the frame axis, the last one trimmed to last_len frames, torch.istft(n_fft=255, length=L) (zero beyond the
  *   overlap-add length), times `out_scale` (the 1 / audio_scale factor of :561-563).  wave: [U, L].
- * wm_wave_attack: the state-free waveform attacks of the evaluation loop on whole utterances: flags bit1 AWGN at
- *   snr_db (audio_attack.py:99-125; Philox noise), bit3 amplitude scaling (:55-58).  power: [U] floats scratch. */
+ * wm_wave_attack: the state-free waveform attacks of the evaluation loop on whole utterances (rows N2 / N3), one per
+ *   call as audio_test.py:628-660 dispatches them, or combined in this order: bit1 AWGN at snr_db
+ *   (audio_attack.py:99-125; Philox noise), bit3 amplitude scaling (:55-58), bit4 echo addition out[i] += echo_gain *
+ *   in[i - echo_delay] (:33-52), bit6 8-bit requantisation rint(clip(x, -1, 1) * 127) / 128 (the PCM_U8 write / read of
+ *   :85-96), bit5 jittering_2: jitter_count uniformly drawn samples zeroed (:176-193).  power: [U] floats scratch. */
+typedef struct WmWaveAttack {
+  int32_t flags; float snr_db; float amp; float echo_gain; int64_t echo_delay; int32_t jitter_count; int32_t reserved;
+  uint64_t seed;
+} WmWaveAttack;
 int32_t wm_stft255_frames(int64_t L);
 int32_t wm_stft255_tiles_per_utterance(int64_t L);
 int wm_stft255_tiles(const float* wave, int64_t L, int32_t U, float* tiles, float scale, void* stream);
 int wm_istft255_stitch(const float* tiles, int32_t n_tiles, int32_t last_len, int32_t U, float* wave, int64_t L,
                        float out_scale, void* stream);
-int wm_wave_attack(const float* wave, float* out, int64_t L, int32_t U, int32_t flags, float snr_db, float amp,
-                   uint64_t seed, float* power, void* stream);
+int wm_wave_attack(const WmWaveAttack* a, const float* wave, float* out, int64_t L, int32_t U, float* power, void* stream);
 
 /* ---- in-graph STFT round trip — torch.istft / torch.stft with n_fft=255, hop 63, rectangular
  * window, center/reflect (model.py:2458,2463).  spec: [B,2,128,128] (re|im planes), wave: [B,8002] */

@@ -11,6 +11,7 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  Follows /root/reference/uformerWM
                              restated here and pinned against scipy.signal.resample_poly.
   awgn              :99-125  noise power from the per-waveform signal power; the random stream itself is
                              PARITY UNPINNED by design (np.random.normal), the caller supplies z ~ N(0,1).
+  echo_addition :33-52, jittering_2 :176-193, requantization :85-96 — evaluation-loop attacks (row N3), see below.
 All functions act on the last axis of an array [..., L].
 """
 import numpy as np
@@ -124,6 +125,32 @@ def awgn_sigma(x, snr_db):
 
 def awgn(x, snr_db, z):
     return np.asarray(x, dtype=np.float64) + awgn_sigma(x, snr_db) * z
+
+
+# ---- state-free attacks of the evaluation loop -----------------------------------
+def echo_addition(x, fs=16000, td=0.5, aa=0.2):
+    """audio_attack.py:33-52: x + aa * (x delayed by td * fs samples)."""
+    x = np.asarray(x, dtype=np.float64)
+    d = int(td * fs)
+    echo = np.concatenate([np.zeros(d), aa * x[:len(x) - d]]) if len(x) > d else np.zeros(len(x))
+    return x + echo
+
+
+def jittering_2(x, indices):
+    """audio_attack.py:176-193 with the drawn positions supplied by the caller (random.randint there: PARITY UNPINNED
+    stream, like awgn)."""
+    y = np.array(x, dtype=np.float64)
+    y[np.asarray(indices, dtype=np.int64)] = 0
+    return y
+
+
+def requantization(x):
+    """audio_attack.py:85-96: soundfile write as PCM_U8 and read back.  libsndfile (absent here, unpinned in the
+    reference => PARITY UNPINNED) converts float -> u8 as lrintf(x * 127) + 128 and u8 -> float as (v - 128) / 128
+    (its pcm.c f2uc_array / uc2f_array, normalised mode); inputs are clipped to [-1, 1] first (libsndfile without
+    clipping wraps there).  fp32 arithmetic like the library."""
+    v = np.clip(np.asarray(x, dtype=np.float32), -1.0, 1.0) * np.float32(127.0)
+    return (np.rint(v) / np.float32(128.0)).astype(np.float32)
 
 
 def attack_chain(x, resample=False, snr_db=None, z=None, lowpass=False, amp=None):

@@ -92,6 +92,29 @@ def test_wave_attack_amplitude_and_awgn(wm):
     assert torch.allclose(both, wm.ops.wave_attack(w, snr_db=20.0, seed=3) * 0.5)
 
 
+def test_wave_attack_echo_jitter_requantization(wm):
+    from oracle import attacks as A
+    L = 30011
+    w = torch.as_tensor(chirp_wave(L, "n3"), dtype=torch.float32)
+    w = (w / w.abs().max() * 1.2).reshape(1, L)                                # beyond [-1, 1]: requantisation clips
+    echo = wm.ops.wave_attack(w.cuda(), echo=(8000, 0.2))
+    assert rel(echo[0], A.echo_addition(w[0].numpy())) <= 1e-6
+    short = wm.ops.wave_attack(w[:, :5000].contiguous().cuda(), echo=(8000, 0.2))          # shorter than the delay
+    assert torch.equal(short.cpu(), w[:, :5000])
+    rq = wm.ops.wave_attack(w.cuda(), requantize=True)
+    assert np.array_equal(rq[0].cpu().numpy(), A.requantization(w[0].numpy()))             # bit exact
+    assert rq.abs().max().item() <= 127 / 128
+    jit = wm.ops.wave_attack(w.cuda(), jitter=1000, seed=9).cpu()
+    hit = (jit != w)[0]
+    assert 950 <= int(hit.sum()) <= 1000 and torch.count_nonzero(jit[0][hit]) == 0         # collisions are rare
+    idx = torch.nonzero(hit)[:, 0].numpy()
+    assert np.array_equal(jit[0].numpy(), A.jittering_2(w[0].numpy(), idx).astype(np.float32))
+    assert torch.equal(jit, wm.ops.wave_attack(w.cuda(), jitter=1000, seed=9).cpu())
+    assert 0.2 < idx.mean() / L < 0.8 and idx.min() < L // 10 and idx.max() > L - L // 10    # spread over the utterance
+    for name in ("echo_addition", "jittering_2-100", "requantization"):
+        assert wm.evaluate._attack(w.cuda(), name, 1).shape == (1, L)
+
+
 def test_signaltonoise(wm):
     a = torch.as_tensor(chirp_wave(5000, "snr"), dtype=torch.float32) + 0.01
     assert abs(wm.evaluate.signaltonoise(a.cuda()) - E.signaltonoise(a.numpy())) < 1e-3
