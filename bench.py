@@ -89,6 +89,8 @@ def main():
                     help="10: config 5 (10 s clips = 10 tiles each, 64x64 grayscale payload as four quadrants; --batch must be a multiple of 10)")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--segmented", action="store_true",
+                    help="capture the step as the multi-rank chain of graphs (cut at the gradient buckets) on one rank too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-shape GEMM timing table on stderr")
@@ -115,7 +117,8 @@ def main():
     opt = wm.FusedAdamW(net, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
     attack = wm.AttackConfig.full_stack() if a.attack == "full" else None
     extract_from = "attacked" if attack is not None else "y"
-    step = wm.TrainStep(net, opt, a.batch, attack=attack, extract_from=extract_from, use_graph=not a.no_graph)
+    step = wm.TrainStep(net, opt, a.batch, attack=attack, extract_from=extract_from, use_graph=not a.no_graph,
+                        segmented=a.segmented)
     g = torch.Generator().manual_seed(42 + rank)
     # waveform in: the data-prep STFT runs on the device (row A1).  A clip of 128 * k frames gets one extra all-zero tile
     # from the reference's padding rule (audio_test.py:476-477); it carries no audio and is dropped here
@@ -181,7 +184,8 @@ def main():
                                 + ("full audio_attack stack (resample+AWGN20dB+low-pass+amp0.8)" if attack else "Identity attack")
                                 + f", {a.mode}"),
                    "tiles_per_gpu": a.batch, "global_tiles": world * a.batch, "audio_sec_per_tile": TILE_SECONDS,
-                   "parallelism": f"dp{world}", "graph": step.use_graph, "params_M": 68.71},
+                   "parallelism": f"dp{world}", "graph": step.use_graph,
+                   "graph_segments": (4 if step.segmented else 1) if step.use_graph else 0, "params_M": 68.71},
         "loss_terms": losses[:5],
     }
     if ref_batch is not None:

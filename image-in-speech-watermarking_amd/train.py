@@ -95,7 +95,8 @@ class TrainStep:
     l1, l2, l3, l4, total, ||noise||) so nothing forces a host sync.
     """
 
-    def __init__(self, net, opt, batch, attack=None, extract_from="y", use_graph=True, process_group=None):
+    def __init__(self, net, opt, batch, attack=None, extract_from="y", use_graph=True, process_group=None,
+                 segmented=False):
         self.net, self.opt, self.B = net, opt, int(batch)
         self.attack, self.extract_from = attack, extract_from
         dev = net._flat.device
@@ -108,13 +109,20 @@ class TrainStep:
         self.world = self.sync.world
         if self.world > 1:
             opt.grad_scale_t.fill_(1.0 / self.world)          # all-reduce(sum) then scale == mean
-        self.use_graph = bool(use_graph) and self.world == 1
+        self.use_graph = bool(use_graph)
+        # with more than one rank the step is captured as a chain of graphs cut at the gradient-bucket boundaries: the
+        # RCCL all-reduces stay outside the captures and are issued between the replays (``segmented`` forces the same
+        # structure on one rank, for tests)
+        self.segmented = bool(segmented) or self.world > 1
         self._graph = None
+        self._segments = None
         self.outputs = None
 
     # -- the launch sequence (no host syncs, no python-side data dependence) ------------------------
-    def _launch(self):
+    def _launch(self, after_segment=None, before_optimizer=None):
         net, B = self.net, self.B
+        if after_segment is None and self.world > 1:
+            after_segment, before_optimizer = self.sync.after_segment, self.sync.finish
         ops.zero_(net._flat_grad)
         ops.step_inc(net._step_t)                               # advances the DropPath / AWGN Philox streams
         outs, S = net._forward_impl(self.x, self.msg, train=net.training, keep_scales=None, attack=self.attack,
@@ -122,8 +130,9 @@ class TrainStep:
         d = [torch.empty_like(o) for o in outs]
         ops.loss_fwd_bwd(outs[0], self.x, outs[1], outs[2], outs[3], self.msg, self.losses, d[0], d[1], d[2], d[3], B,
                          self._scratch)
-        net._backward_impl(S, d[0], d[1], d[2], d[3], after_segment=self.sync.after_segment if self.world > 1 else None)
-        self.sync.finish()
+        net._backward_impl(S, d[0], d[1], d[2], d[3], after_segment=after_segment)
+        if before_optimizer is not None:
+            before_optimizer()
         self.opt.launch()
         self.outputs = outs
         self._tape = S if getattr(self, 'keep_tape', False) else None
@@ -136,15 +145,59 @@ class TrainStep:
         if not self.use_graph:
             self._launch()
             return
+        if self.segmented:
+            if self._segments is None:
+                self._warm_up()
+                self._capture_segments()
+                return                                          # as below: the warm-up pass was this call's step
+            self._replay_segments()
+            return
         if self._graph is None:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):                          # warm-up outside capture (lazy inits, hipFuncSetAttribute)
-                self._launch()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
+            self._warm_up()
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._launch()
             return                                              # the capture pass itself does not execute: replay next
         self._graph.replay()
+
+    def _warm_up(self):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                              # outside capture (lazy inits, hipFuncSetAttribute)
+            self._launch()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+
+    def _capture_segments(self):
+        """Capture the launch sequence as graphs cut where backward has finished a gradient bucket.  Nothing executes
+        during the pass and no collective is recorded: ``_replay_segments`` issues the all-reduce of bucket i after
+        graph i.  All graphs allocate from one pool, replayed in capture order, so tensors that live across a cut keep
+        their addresses."""
+        graphs, cuts = [torch.cuda.CUDAGraph()], []
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+
+        def cut(idx):
+            graphs[-1].capture_end()
+            cuts.append(idx)
+            graphs.append(torch.cuda.CUDAGraph())
+            graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
+
+        with torch.cuda.stream(side):
+            graphs[0].capture_begin(capture_error_mode="thread_local")
+            try:
+                self._launch(after_segment=cut, before_optimizer=lambda: None)
+            finally:
+                graphs[-1].capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._segments = (graphs, cuts)
+
+    def _replay_segments(self):
+        graphs, cuts = self._segments
+        for i, g in enumerate(graphs):
+            g.replay()
+            if i < len(cuts):
+                self.sync.after_segment(cuts[i])
+                if i == len(cuts) - 1:
+                    self.sync.finish()                          # the last graph (tail of backward + AdamW) waits for the collectives

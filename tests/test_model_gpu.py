@@ -176,3 +176,30 @@ def test_train_step_graph_replay_equals_eager_and_learns(wm):
     assert all(torch.isfinite(a).all() for a in l1) and not torch.equal(l1[0], l1[-1])
     assert rel(m1._flat[:m1.optimized_numel], m2._flat[:m2.optimized_numel].cpu()) < 1e-3
     assert int(o1.step_t.item()) == 4
+
+
+def test_train_step_segmented_graphs_equal_single_graph(wm):
+    """The multi-rank form of the step (graphs cut at the gradient-bucket boundaries, collectives issued between the
+    replays) run on one rank: same numbers as the single captured graph, four graphs, three cuts in bucket order."""
+    def make():
+        m = wm.UformerAudio(modulator=True, drop_path_rate=0.1)
+        load_synth(m)
+        m = m.cuda().train()
+        return m, wm.FusedAdamW(m, lr=2e-4)
+    x, msg = synth_tile(2, "sg_x").cuda(), synth_bits("sg_msg", (2, 1, 32, 32)).cuda()
+    (m1, o1), (m2, o2) = make(), make()
+    s1 = wm.TrainStep(m1, o1, 2, use_graph=True)
+    s2 = wm.TrainStep(m2, o2, 2, use_graph=True, segmented=True)
+    l1, l2 = [], []
+    for _ in range(5):
+        s1.step(x, msg)
+        s2.step(x, msg)
+        l1.append(s1.losses.cpu().clone())
+        l2.append(s2.losses.cpu().clone())
+    graphs, cuts = s2._segments
+    assert len(graphs) == 4 and cuts == [0, 1, 2]
+    for a, b in zip(l1, l2):
+        assert torch.allclose(a[:5], b[:5], rtol=2e-3, atol=1e-5), (a, b)
+    assert not torch.equal(l2[0], l2[-1])
+    assert rel(m1._flat[:m1.optimized_numel], m2._flat[:m2.optimized_numel].cpu()) < 1e-3
+    assert int(o2.step_t.item()) == 5
