@@ -148,7 +148,13 @@ class TrainStep:
         if self.segmented:
             if self._segments is None:
                 self._warm_up()
-                self._capture_segments()
+                try:
+                    self._capture_segments()
+                except RuntimeError as e:                       # same HIP launches, just not captured: say so and go on
+                    import sys
+                    print(f"[TrainStep] segmented graph capture failed ({e}); running the step un-captured", file=sys.stderr)
+                    torch.cuda.synchronize()
+                    self.use_graph = False
                 return                                          # as below: the warm-up pass was this call's step
             self._replay_segments()
             return
@@ -187,8 +193,13 @@ class TrainStep:
             graphs[0].capture_begin(capture_error_mode="thread_local")
             try:
                 self._launch(after_segment=cut, before_optimizer=lambda: None)
-            finally:
-                graphs[-1].capture_end()
+            except BaseException:
+                try:
+                    graphs[-1].capture_end()                    # leave capture mode before reporting
+                except RuntimeError:
+                    pass
+                raise
+            graphs[-1].capture_end()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._segments = (graphs, cuts)
