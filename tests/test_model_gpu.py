@@ -203,3 +203,35 @@ def test_train_step_segmented_graphs_equal_single_graph(wm):
     assert not torch.equal(l2[0], l2[-1])
     assert rel(m1._flat[:m1.optimized_numel], m2._flat[:m2.optimized_numel].cpu()) < 1e-3
     assert int(o2.step_t.item()) == 5
+
+
+def test_resume_from_reference_format_checkpoint(wm, tmp_path):
+    """A checkpoint in the reference's format (torch AdamW state after one oracle step, DataParallel key prefix) is
+    loaded into the model + fused optimizer; the next step matches the oracle's next step (nonzero moments, step = 2)."""
+    from collections import OrderedDict
+    ref = load_synth(O.UformerAudio()).train()
+    opt = torch.optim.AdamW(ref.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    x, msg = synth_tile(2, "rs_x"), synth_bits("rs_msg", (2, 1, 32, 32))
+
+    def ref_step():
+        opt.zero_grad()
+        loss, _ = O.train_losses(ref(x, msg), x, msg)
+        loss.backward()
+        opt.step()
+        return loss.item()
+    ref_step()
+    path = wm.checkpoint.save_checkpoint(str(tmp_path), {
+        "epoch": 1, "optimizer": opt.state_dict(),
+        "state_dict": OrderedDict(("module." + k, v) for k, v in ref.state_dict().items())}, "resume")
+    m = wm.UformerAudio(modulator=True, drop_path_rate=0.0).cuda().train()
+    m.compute_mode = "fp32"
+    fused = wm.FusedAdamW(m, lr=1e-3)
+    wm.checkpoint.load_checkpoint(m, path)
+    assert wm.checkpoint.load_optim(fused, path) == 2e-4
+    step = wm.TrainStep(m, fused, 2, use_graph=False)
+    loss2 = ref_step()
+    step.step(x.cuda(), msg.cuda())
+    assert abs(step.losses[4].item() - loss2) <= 1e-4 * abs(loss2)
+    assert int(fused.step_t.item()) == 2
+    worst = max(rel(m.state_dict()[k], v) for k, v in ref.state_dict().items() if v.dtype.is_floating_point)
+    assert worst <= 2e-4, worst
