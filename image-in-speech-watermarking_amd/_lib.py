@@ -40,7 +40,8 @@ class WmConv(C.Structure):
 
 class WmAttack(C.Structure):
     _fields_ = [("flags", c_i32), ("snr_db", c_fl), ("amp", c_fl), ("lp_h", c_f), ("lp_n", c_i32),
-                ("rs_h", c_f), ("rs_n", c_i32), ("seed", c_u64), ("step", c_f)]
+                ("rs_h", c_f), ("rs_n", c_i32), ("seed", c_u64), ("step", c_f),
+                ("echo_delay", c_i32), ("echo_gain", c_fl), ("jitter_count", c_i32), ("reserved", c_i32)]
 
 
 class WmWaveAttack(C.Structure):

@@ -55,11 +55,15 @@ class AttackConfig:
     lowpass: bool = False
     amp: Optional[float] = None
     seed: int = 7
+    echo: Optional[tuple] = None          # (delay in samples, gain): audio_attack.py:33-52 uses (8000, 0.2)
+    jitter: Optional[int] = None          # number of zeroed samples per row (jittering_2, :176-193)
+    requantize: bool = False              # 8-bit PCM round trip (:85-96), straight-through gradient
 
     @property
     def flags(self):
         return (1 if self.resample else 0) | (2 if self.snr_db is not None else 0) | (4 if self.lowpass else 0) | \
-               (8 if self.amp is not None else 0)
+               (8 if self.amp is not None else 0) | (16 if self.echo is not None else 0) | \
+               (32 if self.jitter is not None else 0) | (64 if self.requantize else 0)
 
     @staticmethod
     def identity():
@@ -86,6 +90,12 @@ class AttackConfig:
                 cfg.lowpass = True
             elif name in ("amplitude", "amplitude_scaling"):
                 cfg.amp = float(param) if param else 0.8
+            elif name == "echo_addition":
+                cfg.echo = (int(param), 0.2) if param else (8000, 0.2)
+            elif name == "jittering_2":
+                cfg.jitter = int(param) if param else 1000
+            elif name == "requantization":
+                cfg.requantize = True
             else:
                 raise ValueError(f"attack '{name}' is outside the MI355X hot path (see DESIGN.md, out of scope)")
         return cfg
@@ -103,8 +113,9 @@ def _device_tables(device):
 
 def _desc(cfg, device, step):
     lp, rs = _device_tables(device)
+    delay, gain = cfg.echo if cfg.echo is not None else (0, 0.0)
     return WmAttack(cfg.flags, float(cfg.snr_db or 0.0), float(cfg.amp if cfg.amp is not None else 1.0), ptr(lp),
-                    LP_TAPS, ptr(rs), 41, int(cfg.seed), ptr(step))
+                    LP_TAPS, ptr(rs), 41, int(cfg.seed), ptr(step), int(delay), float(gain), int(cfg.jitter or 0), 0)
 
 
 def attack_forward(cfg, wave, step, out=None, sigma=None):

@@ -110,6 +110,13 @@ __device__ __forceinline__ void gauss4(uint64_t seed, uint64_t step, uint32_t ro
   sincospif(2.0f * u3, &s, &c); z[2] = m1 * c; z[3] = m1 * s;
 }
 
+// jittering_2: the j-th zeroed position of a row; its own Philox stream (key differs from the AWGN stream's)
+__device__ __forceinline__ int jitter_index(uint64_t seed, uint64_t step, uint32_t row, uint32_t j, int L) {
+  uint32_t r[4];
+  philox4x32(j, row, (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed ^ 0x6a17c0deu, (uint32_t)(seed >> 32), r);
+  return (int)(((uint64_t)r[0] * (uint64_t)L) >> 32);
+}
+
 __global__ __launch_bounds__(NT) void attack_fwd_kernel(const WmAttack a, const float* __restrict__ wave,
                                                         float* __restrict__ out, float* __restrict__ sigma_out,
                                                         int L) {
@@ -165,7 +172,28 @@ __global__ __launch_bounds__(NT) void attack_fwd_kernel(const WmAttack a, const 
     off = PADLEN;
   }
   const float amp = (a.flags & 8) ? a.amp : 1.0f;
-  for (int i = tid; i < L; i += NT) out[(int64_t)row * L + i] = amp * cur[off + i];
+  if (!(a.flags & (16 | 32 | 64))) {
+    for (int i = tid; i < L; i += NT) out[(int64_t)row * L + i] = amp * cur[off + i];
+    return;
+  }
+  // row N3 stages, after the amplitude scale: echo addition -> jittering_2 -> 8-bit requantisation
+  const int d = (a.flags & 16) ? a.echo_delay : L;
+  for (int i = tid; i < L; i += NT) {
+    float v = amp * cur[off + i];
+    if (i >= d) v += a.echo_gain * amp * cur[off + i - d];
+    oth[i] = v;
+  }
+  __syncthreads();
+  if (a.flags & 32) {
+    const uint64_t step = a.step ? (uint64_t)*a.step : 0ull;
+    for (int j = tid; j < a.jitter_count; j += NT) oth[jitter_index(a.seed, step, (uint32_t)row, (uint32_t)j, L)] = 0.f;
+    __syncthreads();
+  }
+  for (int i = tid; i < L; i += NT) {
+    float v = oth[i];
+    if (a.flags & 64) v = rintf(fminf(fmaxf(v, -1.0f), 1.0f) * 127.0f) * (1.0f / 128.0f);
+    out[(int64_t)row * L + i] = v;
+  }
 }
 
 __global__ __launch_bounds__(NT) void attack_bwd_kernel(const WmAttack a, const float* __restrict__ wave,
@@ -192,10 +220,29 @@ __global__ __launch_bounds__(NT) void attack_bwd_kernel(const WmAttack a, const 
   __syncthreads();
   const float amp = (a.flags & 8) ? a.amp : 1.0f;
   float* g = A; float* oth = Bf;
+  // adjoint of the row-N3 stages (requantisation: straight-through; jitter: the zeroed samples pass no gradient;
+  // echo: g[i] += gain * g[i + delay]); the result replaces dout below
+  const bool tail_stages = (a.flags & (16 | 32)) != 0;
+  if (tail_stages) {
+    for (int i = tid; i < L; i += NT) oth[i] = dout[(int64_t)row * L + i];
+    __syncthreads();
+    if (a.flags & 32) {
+      const uint64_t step = a.step ? (uint64_t)*a.step : 0ull;
+      for (int j = tid; j < a.jitter_count; j += NT) oth[jitter_index(a.seed, step, (uint32_t)row, (uint32_t)j, L)] = 0.f;
+      __syncthreads();
+    }
+  }
+  const int ed = (a.flags & 16) ? a.echo_delay : L;
+  auto dsrc = [&](int i) -> float {
+    if (!tail_stages) return dout[(int64_t)row * L + i];
+    float v = oth[i];
+    if (i + ed < L) v += a.echo_gain * oth[i + ed];
+    return v;
+  };
   if (a.flags & 4) {
     const int N = L + 2 * PADLEN;
     for (int q = tid; q < N; q += NT)
-      g[q] = (q >= PADLEN && q < PADLEN + L) ? amp * dout[(int64_t)row * L + q - PADLEN] : 0.f;
+      g[q] = (q >= PADLEN && q < PADLEN + L) ? amp * dsrc(q - PADLEN) : 0.f;
     __syncthreads();
     // adjoint of the anti-causal pass: causal correlation + tail term onto the last sample
     for (int m = tid; m < N; m += NT) {
@@ -244,7 +291,7 @@ __global__ __launch_bounds__(NT) void attack_bwd_kernel(const WmAttack a, const 
     __syncthreads();
     float* t = g; g = oth; oth = t;
   } else {
-    for (int i = tid; i < L; i += NT) g[i] = amp * dout[(int64_t)row * L + i];
+    for (int i = tid; i < L; i += NT) g[i] = amp * dsrc(i);
     __syncthreads();
   }
   if (a.flags & 2) {
@@ -276,6 +323,9 @@ bool args_ok(const WmAttack* a, int B, int L) {
   if (!a || B <= 0 || L < 64 || L + 2 * PADLEN > BUF) return false;
   if ((a->flags & 4) && (!a->lp_h || a->lp_n < 2 || a->lp_n > 256)) return false;
   if ((a->flags & 1) && (!a->rs_h || a->rs_n != 2 * RS_HALF + 1)) return false;
+  if ((a->flags & 16) && a->echo_delay <= 0) return false;
+  if ((a->flags & 32) && a->jitter_count < 0) return false;
+  if (a->flags & ~127) return false;
   return true;
 }
 size_t smem_bytes(int nbuf, int J) { return sizeof(float) * ((size_t)nbuf * BUF + 2 * J + 48 + 16); }

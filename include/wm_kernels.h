@@ -185,11 +185,15 @@ int wm_stft255_bwd(const float* dspec, float* dwave, int32_t B, void* stream);
 /* ---- waveform attacks (audio_attack.py:21-30,55-58,71-83,99-125; torch awgn model.py:15-41).
  * One workgroup per waveform keeps the row in LDS through the whole chain.
  * flags bit0 resample 16k->8k->16k, bit1 AWGN(snr_db), bit2 low-pass (FIR-expanded Butterworth-8
- * filtfilt, taps `lp_h[lp_n]`), bit3 amplitude scale.  bwd applies the adjoint chain.            */
+ * filtfilt, taps `lp_h[lp_n]`), bit3 amplitude scale; then the SURVEY 8f row-N3 stages on the row: bit4 echo addition
+ * (audio_attack.py:33-52: + echo_gain * row delayed by echo_delay samples), bit5 jittering_2 (:176-193: jitter_count
+ * uniformly drawn samples zeroed), bit6 8-bit requantisation (:85-96: rint(clip(x,-1,1) * 127) / 128, straight-through
+ * gradient).  bwd applies the adjoint chain.                                                                        */
 typedef struct WmAttack {
   int32_t flags; float snr_db; float amp; const float* lp_h; int32_t lp_n;
   const float* rs_h; int32_t rs_n;          /* polyphase resampling prototype filter              */
   uint64_t seed; const int64_t* step;       /* Philox stream = (seed, *step, row)                 */
+  int32_t echo_delay; float echo_gain; int32_t jitter_count; int32_t reserved;
 } WmAttack;
 int wm_attack_fwd(const WmAttack* a, const float* wave, float* out, float* sigma_out, int32_t B, int32_t L,
                   void* stream);

@@ -153,8 +153,10 @@ def requantization(x):
     return (np.rint(v) / np.float32(128.0)).astype(np.float32)
 
 
-def attack_chain(x, resample=False, snr_db=None, z=None, lowpass=False, amp=None):
-    """Order fixed by SURVEY.md 8(d): resample -> AWGN -> low-pass -> amplitude scale."""
+def attack_chain(x, resample=False, snr_db=None, z=None, lowpass=False, amp=None, echo=None, jitter_idx=None,
+                 requantize=False):
+    """Order fixed by SURVEY.md 8(d): resample -> AWGN -> low-pass -> amplitude scale; then the row-N3 stages
+    echo (delay, gain) -> jittering_2 (per-row index lists) -> 8-bit requantisation.  x: [rows, L]."""
     x = np.asarray(x, dtype=np.float64)
     if resample:
         x = resampling(x)
@@ -164,4 +166,11 @@ def attack_chain(x, resample=False, snr_db=None, z=None, lowpass=False, amp=None
         x = low_pass(x)
     if amp is not None:
         x = amplitude_scaling(x, amp)
+    if echo is not None:
+        d, g = echo
+        x = np.stack([echo_addition(r, fs=1, td=d, aa=g) for r in np.atleast_2d(x)]).reshape(x.shape)
+    if jitter_idx is not None:
+        x = np.stack([jittering_2(r, i) for r, i in zip(np.atleast_2d(x), jitter_idx)]).reshape(x.shape)
+    if requantize:
+        x = requantization(x).astype(np.float64)
     return x

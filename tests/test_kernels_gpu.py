@@ -440,6 +440,52 @@ def test_attacks_fwd_and_adjoint(wm):
     assert abs(fd - (dgr * v).sum()) <= 2e-3 * abs(fd) + 1e-6
 
 
+def test_attack_row_n3_stages_fwd_and_adjoint(wm):
+    """In-loop echo / jittering_2 / requantisation behind the four BASELINE attacks."""
+    att = wm.attacks
+    B, L = 3, 8002
+    x = 0.4 * synth_array("n3x", (B, L))
+    xd = dev(x)
+    step = torch.full((1,), 5, dtype=torch.int64, device="cuda")
+    # echo after low-pass + amplitude scale, against the oracle chain
+    c = att.AttackConfig(lowpass=True, amp=0.8, echo=(3000, 0.2))
+    o, _ = att.attack_forward(c, xd, step)
+    assert_close(o, torch.from_numpy(OA.attack_chain(x.numpy(), lowpass=True, amp=0.8, echo=(3000, 0.2))), 1e-4, "echo")
+    # requantisation alone: bit exact against the PCM_U8 rule
+    big = 3.0 * x
+    o, _ = att.attack_forward(att.AttackConfig(requantize=True), dev(big), step)
+    assert np.array_equal(o.cpu().numpy(), OA.requantization(big.numpy()))
+    # jitter: positions read back from the output, replayed through the oracle; deterministic in (seed, step)
+    cj = att.AttackConfig(amp=0.5, jitter=300, seed=11)
+    o, _ = att.attack_forward(cj, xd, step)
+    hit = (o.cpu() == 0) & (x != 0)
+    counts = hit.sum(1)
+    assert ((counts >= 280) & (counts <= 300)).all(), counts
+    idx = [torch.nonzero(h)[:, 0].numpy() for h in hit]
+    assert_close(o, torch.from_numpy(OA.attack_chain(x.numpy(), amp=0.5, jitter_idx=idx)), 1e-6, "jitter")
+    assert not np.array_equal(idx[0], idx[1])                                   # rows draw their own positions
+    o2, _ = att.attack_forward(cj, xd, step)
+    assert torch.equal(o, o2)
+    o3, _ = att.attack_forward(cj, xd, step + 1)
+    assert not torch.equal(o, o3)
+    # all three together with the full BASELINE stack in front: runs, finite, 8-bit grid
+    full = att.AttackConfig(True, 20.0, True, 0.8, 7, echo=(4000, 0.2), jitter=100, requantize=True)
+    o, sg = att.attack_forward(full, xd, step)
+    assert torch.isfinite(o).all() and torch.equal(o * 128, (o * 128).round())
+    # backward = exact adjoint of the linear stages (echo + jitter mask behind resample / low-pass / amp)
+    lin = att.AttackConfig(resample=True, lowpass=True, amp=0.8, echo=(3000, 0.2), jitter=200, seed=3)
+    g = synth_array("n3g", (B, L))
+    ax, _ = att.attack_forward(lin, xd, step)
+    atg = att.attack_backward(lin, xd, dev(g), None, step)
+    lhs = (ax.double().cpu() * g.double()).sum(-1)
+    rhs = (x.double() * atg.double().cpu()).sum(-1)
+    assert_close(lhs, rhs, 1e-4, "row-N3 adjoint")
+    # requantisation passes the gradient straight through
+    ga = att.attack_backward(att.AttackConfig(amp=0.8, requantize=True), xd, dev(g), None, step)
+    assert_close(ga, 0.8 * g, 1e-6, "requantisation straight-through")
+    assert att.AttackConfig.from_string("echo_addition+jittering_2-50+requantization").flags == 16 | 32 | 64
+
+
 # ------------------------------------------------------------------------------- loss, AdamW, rng
 def test_loss_fwd_bwd(wm):
     ops = wm.ops
