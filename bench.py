@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-shape GEMM timing table on stderr")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="run the N-rank code path with every rank on GPU 0 over gloo (a functional rehearsal on a one-GPU "
+                         "box: RCCL refuses two ranks per device; the numbers mean nothing)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,11 +104,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the watermark hot path has no CPU fallback")
+    if a.rehearse_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     wm = importlib.import_module("image-in-speech-watermarking_amd")
     from synth import load_synth
 
