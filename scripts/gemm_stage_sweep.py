@@ -13,6 +13,10 @@ rows = []
 for hw, C in ((128, 32), (64, 64), (32, 128), (16, 256), (8, 512), (128, 64), (64, 128), (32, 256), (16, 512)):
     M = B * hw * hw
     for name, N, K, res in (("qkv", 3 * C, C, 0), ("proj", C, C, 1), ("fc1", 4 * C, C, 0), ("fc2", C, 4 * C, 1)):
+        if os.environ.get("ONLY") and name not in os.environ["ONLY"].split(","):
+            continue
+        if os.environ.get("MAXC") and C > int(os.environ["MAXC"]):
+            continue
         by = M * K * 2 + N * K * 2 + M * N * (4 + 4 if res else 2)
         nrot = max(2, int(700e6 // by) + 1)
         bufs = []
