@@ -67,25 +67,36 @@ def _attack(wave, attack, seed):
     raise NotImplementedError(f"attack '{name}' is a CPU tool of audio_attack.py outside the MI355X path (DESIGN.md, out of scope)")
 
 
-@torch.no_grad()
-def reconstruct_audio(audio_data, watermark, model, n_fft=255, attack=None, data_mode="stft", audio_scale="0",
-                      data_min=None, data_max=None, model_name="uformer", batch=32, seed=0):
-    """reconstruct_audio of audio_test.py:528-785 for ``data_mode='stft'``.
+def _snr_rows(w):
+    """signaltonoise of every row of [U, L] as a device tensor of |mean / std| (converted to dB on the host)."""
+    w = w.double()
+    sd = w.std(dim=1, unbiased=False)
+    return torch.where(sd == 0, torch.zeros_like(sd), w.mean(dim=1) / sd).abs()
 
-    Returns ``(audio_att, recon_audio, watermark, wms_decode, wms_att_decode, mse_loss, wm_loss, wm_loss_att,
-    snr_ori, snr_recon)``: tensors stay on the device, the per-tile lists hold ``[1, 1, 32, 32]`` tensors."""
+
+def _db(r):
+    return 20.0 * math.log10(r) if r > 0 else float("-inf")
+
+
+@torch.no_grad()
+def reconstruct_audio_batch(audio_datas, watermark, model, n_fft=255, attack=None, data_mode="stft", audio_scale="0",
+                            model_name="uformer", batch=96, seed=0):
+    """``reconstruct_audio`` for several utterances of EQUAL length in one pass: their tiles share the model batches
+    (the model is 1.5 x more efficient at 96 tiles than at 20), the transforms and attacks take [U, L] waveforms, and
+    all scalar metrics come back in one host read.  Returns one reference-style 10-tuple per utterance."""
     if data_mode != "stft" or n_fft != 255:
         raise ValueError("the MI355X evaluation path covers data_mode='stft' with n_fft=255 (audio_test.py:594-600)")
     if "-" in audio_scale:
         raise ValueError("range-style audio_scale needs dataset statistics: not on this path")
-    wave, clips, len_last_clip = audio_data[0], audio_data[1], int(audio_data[2])
-    if wave.dim() == 1:
-        wave = wave[None]
-    n = clips.shape[0]
-    L = wave.shape[-1]
+    U = len(audio_datas)
+    L, n, len_last_clip = audio_datas[0][0].shape[-1], audio_datas[0][1].shape[0], int(audio_datas[0][2])
+    if any(d[0].shape[-1] != L or d[1].shape[0] != n or int(d[2]) != len_last_clip for d in audio_datas):
+        raise ValueError("reconstruct_audio_batch takes utterances of equal length")
+    waves = torch.cat([d[0].reshape(1, -1) for d in audio_datas]).contiguous()
+    clips = torch.cat([d[1] for d in audio_datas]).contiguous()
     msg = watermark.reshape(1, 1, 32, 32).float()
     enc, dec = [], []
-    for i in range(0, n, batch):                                          # audio_test.py:547-556, batched over tiles
+    for i in range(0, U * n, batch):                                      # audio_test.py:547-556, batched over tiles
         c = clips[i:i + batch].contiguous()
         m = msg.expand(c.shape[0], 1, 32, 32).contiguous()
         if model_name == "uformer":
@@ -98,22 +109,38 @@ def reconstruct_audio(audio_data, watermark, model, n_fft=255, attack=None, data
         dec.append(wm_decode)
     enc, dec = torch.cat(enc).contiguous(), torch.cat(dec)
     factor = 1.0 / float(audio_scale) if len(audio_scale) > 1 else 1.0    # :559-563
-    recon_audio = ops.istft255_stitch(enc, n, len_last_clip, L, factor)   # :594-600
-    mse_loss = _mse(wave.reshape(1, L), recon_audio)                      # :618
-    wm_loss = _mse(msg, dec[n - 1:n])                                     # :625 (the reference keeps the last tile's)
+    recon_audio = ops.istft255_stitch(enc, n, len_last_clip, L, factor)   # :594-600, [U, L]
     audio_att = _attack(recon_audio, attack, seed)                        # :628-660
     scale = float(audio_scale) if len(audio_scale) > 1 else 1.0
     att_clips, _ = ops.stft255_tiles(audio_att.contiguous(), scale)       # :676-700
+    n_att = att_clips.shape[0] // U
     dec_att = []
     for i in range(0, att_clips.shape[0], batch):
         c = att_clips[i:i + batch].contiguous()
         dec_att.append(model.wm_decode(c) if model_name == "uformer" else model.decode(c))
     dec_att = torch.cat(dec_att)
-    losses_att = torch.zeros(dec_att.shape[0], device=wave.device)        # :706, one host read for all tiles
-    for j in range(dec_att.shape[0]):
-        _mse(msg, dec_att[j:j + 1], losses_att[j])
-    scalars = torch.stack([mse_loss, wm_loss, losses_att.mean()]).tolist()
-    snr_ori = signaltonoise(wave)
-    snr_recon = signaltonoise(recon_audio)
-    return (audio_att.reshape(-1), recon_audio.reshape(-1), watermark, [dec[j:j + 1] for j in range(n)],
-            [dec_att[j:j + 1] for j in range(dec_att.shape[0])], scalars[0], scalars[1], scalars[2], snr_ori, snr_recon)
+    scal = torch.zeros(U, 2 + n_att, device=waves.device)                 # mse_loss | wm_loss | wm_losses_att...
+    for u in range(U):
+        _mse(waves[u:u + 1], recon_audio[u:u + 1], scal[u, 0])            # :618
+        _mse(msg, dec[(u + 1) * n - 1:(u + 1) * n], scal[u, 1])           # :625 (the reference keeps the last tile's)
+        for j in range(n_att):
+            _mse(msg, dec_att[u * n_att + j:u * n_att + j + 1], scal[u, 2 + j])          # :706
+    host = torch.cat([scal.double(), _snr_rows(waves)[:, None], _snr_rows(recon_audio)[:, None]], dim=1).tolist()
+    out = []
+    for u in range(U):
+        h = host[u]
+        out.append((audio_att[u], recon_audio[u], watermark, [dec[u * n + j:u * n + j + 1] for j in range(n)],
+                    [dec_att[u * n_att + j:u * n_att + j + 1] for j in range(n_att)], h[0], h[1],
+                    sum(h[2:2 + n_att]) / n_att, _db(h[-2]), _db(h[-1])))
+    return out
+
+
+@torch.no_grad()
+def reconstruct_audio(audio_data, watermark, model, n_fft=255, attack=None, data_mode="stft", audio_scale="0",
+                      data_min=None, data_max=None, model_name="uformer", batch=32, seed=0):
+    """reconstruct_audio of audio_test.py:528-785 for ``data_mode='stft'``.
+
+    Returns ``(audio_att, recon_audio, watermark, wms_decode, wms_att_decode, mse_loss, wm_loss, wm_loss_att,
+    snr_ori, snr_recon)``: tensors stay on the device, the per-tile lists hold ``[1, 1, 32, 32]`` tensors."""
+    return reconstruct_audio_batch([audio_data], watermark, model, n_fft=n_fft, attack=attack, data_mode=data_mode,
+                                   audio_scale=audio_scale, model_name=model_name, batch=batch, seed=seed)[0]

@@ -55,6 +55,15 @@ def main():
         dt = time.perf_counter() - t0
         out[f"reconstruct_audio[{attack}]_audio_s_per_s"] = U * L / 16000 / dt
         out[f"reconstruct_audio[{attack}]_ms_per_utterance"] = 1e3 * dt / U
+    for attack in ("closed_loop", "awgn-20"):
+        wm.evaluate.reconstruct_audio_batch(data[:4], msg, net, attack=attack)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(0, U, 4):
+            wm.evaluate.reconstruct_audio_batch(data[i:i + 4], msg, net, attack=attack)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[f"reconstruct_audio_batch4[{attack}]_audio_s_per_s"] = U * L / 16000 / dt
     print(json.dumps(out))
 
 

@@ -148,6 +148,32 @@ def test_reconstruct_audio_matches_oracle_loop(wm, attack, scale):
         assert abs(10 ** (g[i] / 20) - 10 ** (r[i] / 20)) < 1e-4, (i, g[i], r[i])
 
 
+def test_reconstruct_audio_batch_equals_single_calls(wm):
+    """Three equal-length utterances in one pass (shared model batches, [U, L] transforms) == three single calls."""
+    net = wm.UformerAudio(modulator=True)
+    load_synth(net)
+    net = net.cuda().eval()
+    net.compute_mode = "fp32"
+    L = 9000
+    msg = synth_bits("rb_msg", (1, 1, 32, 32)).cuda()
+    data = [wm.evaluate.prepare_utterance(torch.as_tensor(chirp_wave(L, f"rb{i}"), dtype=torch.float32).reshape(1, L).cuda())
+            for i in range(3)]
+    both = wm.evaluate.reconstruct_audio_batch(data, msg, net, attack="amplitude_scaling-0.8", batch=4)
+    for d, b in zip(data, both):
+        one = wm.evaluate.reconstruct_audio(d, msg, net, attack="amplitude_scaling-0.8")
+        assert rel(b[0], one[0].cpu()) <= 1e-5 and rel(b[1], one[1].cpu()) <= 1e-5
+        assert len(b[3]) == len(one[3]) and len(b[4]) == len(one[4])
+        for x, y in zip(b[3] + b[4], one[3] + one[4]):
+            assert rel(x, y.cpu()) <= 1e-5
+        for i in (5, 6, 7):
+            assert abs(b[i] - one[i]) <= 1e-5 * max(abs(one[i]), 1e-6)
+        for i in (8, 9):
+            assert abs(10 ** (b[i] / 20) - 10 ** (one[i] / 20)) < 1e-6
+    with pytest.raises(ValueError):
+        wm.evaluate.reconstruct_audio_batch(
+            [data[0], wm.evaluate.prepare_utterance(torch.zeros(1, 20000, device="cuda"))], msg, net)
+
+
 def test_out_of_path_attacks_raise(wm):
     wave = torch.zeros(1, 9000, device="cuda")
     with pytest.raises(NotImplementedError):
