@@ -24,7 +24,7 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 #define TN_NBUF 1
 #endif
 #ifndef TN_TARGET
-#define TN_TARGET 768
+#define TN_TARGET 512
 #endif
 
 // MFMA 32x32x16 operand out of an as-it-lies [k][columns] LDS image (lane l: column l&31, k = 8*(l>>5) + j)
