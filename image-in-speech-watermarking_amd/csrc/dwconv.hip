@@ -174,6 +174,116 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ST* __restrict__ 
   }
 }
 
+// Strip-walking forward: one workgroup takes the row of tiles (b, ty, *) of 64 channels.  The halo image in LDS is a ring
+// of 16 pixel columns (image column gx lives in slot (gx + 1) & 15): moving to the next tile only adds its 8 new columns,
+// so the first GELU runs on 10 x 8 instead of 10 x 10 pixels per tile (2.25 instead of 2.56 evaluations per output with
+// the second GELU), and the next tile's columns are in flight while the current tile is computed.
+constexpr int RING = 16;
+template <typename ST> struct Cols {                          // the 8 new columns of a tile: HP rows x TP columns x 64 channels
+  static constexpr int NE = Chunk<ST>::NE, CPP = TC / NE, NCH = HP * TP * CPP, NL = (NCH + 255) / 256;
+};
+// columns [gx0, gx0 + ncols) of rows ty * TP - 1 .. ty * TP + TP into registers (out-of-image pixels become zero)
+template <typename ST>
+__device__ __forceinline__ void cols_load(u32x4 (&c)[Cols<ST>::NL], const ST* __restrict__ src, int b, int ty, int gx0,
+                                          int hw, int Ch, int cbase, int tid) {
+  typedef Cols<ST> H;
+#pragma unroll
+  for (int k = 0; k < H::NL; ++k) {
+    int idx = tid + 256 * k;
+    idx = idx < H::NCH ? idx : H::NCH - 1;
+    const int pix = idx / H::CPP, part = idx - pix * H::CPP;
+    const int ly = pix / TP, lx = pix - ly * TP;
+    const int gy = ty * TP + ly - 1, gx = gx0 + lx;
+    const bool inb = (unsigned)gy < (unsigned)hw && (unsigned)gx < (unsigned)hw;
+    const int cy = min(max(gy, 0), hw - 1), cx = min(max(gx, 0), hw - 1);
+    u32x4 v = *reinterpret_cast<const u32x4*>(src + (((int64_t)b * hw + cy) * hw + cx) * Ch + cbase + part * H::NE);
+    if (!inb) v = (u32x4){0u, 0u, 0u, 0u};
+    c[k] = v;
+  }
+}
+// gelu of the staged columns into their ring slots
+template <typename ST>
+__device__ __forceinline__ void cols_to_ring(float* ring, const u32x4 (&c)[Cols<ST>::NL], int gx0, int tid) {
+  typedef Cols<ST> H;
+#pragma unroll
+  for (int k = 0; k < H::NL; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < H::NCH) {
+      const int pix = idx / H::CPP, part = idx - pix * H::CPP;
+      const int ly = pix / TP, lx = pix - ly * TP;
+      float f[H::NE];
+      Chunk<ST>::unpack(c[k], f);
+#pragma unroll
+      for (int i = 0; i < H::NE; i += 2) {
+        f32x2 a, g;
+        gelu_pair((f32x2){f[i], f[i + 1]}, a, g);
+        f[i] = a.x;
+        f[i + 1] = a.y;
+      }
+      float* dst = ring + ((ly * RING + ((gx0 + lx + 1) & (RING - 1))) * TC) + part * H::NE;
+#pragma unroll
+      for (int i = 0; i < H::NE; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(f[i], f[i + 1], f[i + 2], f[i + 3]);
+    }
+  }
+}
+
+template <typename ST>
+__global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restrict__ h1, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, ST* __restrict__ h2,
+                                                               ST* __restrict__ a2, ST* __restrict__ g2, int B, int hw,
+                                                               int Ch) {
+  __shared__ __attribute__((aligned(16))) float ring[HP * RING * TC];
+  __shared__ __attribute__((aligned(16))) float wl[10 * TC];
+  typedef typename Pair<ST>::raw raw;
+  const int tid = threadIdx.x, nt = hw / TP;
+  const int b = blockIdx.x / nt, ty = blockIdx.x % nt;
+  const int cbase = blockIdx.y * TC;
+  const int c2 = tid & 31, py = tid >> 5;
+  u32x4 creg[Cols<ST>::NL];
+  cols_load<ST>(creg, h1, b, ty, -7, hw, Ch, cbase, tid);     // columns -7 .. 0: only column 0 (and the zero column -1) matter
+  stage_weights(wl, w, bias, cbase, tid);
+  cols_to_ring<ST>(ring, creg, -7, tid);                      // zeros for the columns left of the image: gelu(0) = 0
+  cols_load<ST>(creg, h1, b, ty, 1, hw, Ch, cbase, tid);      // tile 0 adds columns 1 .. 8
+  __syncthreads();
+  f32x2 wr[9], br;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wr[k] = *reinterpret_cast<const f32x2*>(wl + k * TC + 2 * c2);
+  br = *reinterpret_cast<const f32x2*>(wl + 9 * TC + 2 * c2);
+  const int64_t strip0 = (((int64_t)b * hw + ty * TP + py) * hw) * Ch + cbase + 2 * c2;
+  for (int tx = 0; tx < nt; ++tx) {
+    __syncthreads();                                          // the previous tile is done with the slots about to be reused
+    cols_to_ring<ST>(ring, creg, tx * TP + 1, tid);
+    __syncthreads();
+    if (tx + 1 < nt) cols_load<ST>(creg, h1, b, ty, (tx + 1) * TP + 1, hw, Ch, cbase, tid);
+    const int s0 = tx * TP;                                   // ring slot of halo column lx: (s0 + lx) & 15
+    f32x2 col[3][3];                                          // col[x % 3][dy]
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+        col[x][dy] = *reinterpret_cast<const f32x2*>(ring + ((py + dy) * RING + ((s0 + x) & (RING - 1))) * TC + 2 * c2);
+#pragma unroll
+    for (int px = 0; px < TP; ++px) {
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+        col[(px + 2) % 3][dy] = *reinterpret_cast<const f32x2*>(ring + ((py + dy) * RING + ((s0 + px + 2) & (RING - 1))) * TC + 2 * c2);
+      f32x2 o = br;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) o += wr[dy * 3 + dx] * col[(px + dx) % 3][dy];
+      const int64_t off = strip0 + (int64_t)(tx * TP + px) * Ch;
+      if (h2) *reinterpret_cast<raw*>(h2 + off) = Pair<ST>::down(o);
+      if (a2 || g2) {
+        f32x2 av, gv;
+        gelu_pair(o, av, gv);
+        if (a2) *reinterpret_cast<raw*>(a2 + off) = Pair<ST>::down(av);
+        if (g2) *reinterpret_cast<raw*>(g2 + off) = Pair<ST>::down(gv);
+      }
+    }
+  }
+}
+
 // dh1 = gelu'(h1) * sum_k w[k] * dh2[p - off_k];  dw[c][k] += sum_q gelu(h1)[q] * dh2[q - off_k];  db += sum dh2.
 // Only dh2 needs a halo: the weight gradient is written as a sum over the CENTRE pixels q of a1[q] * dh2[q - off]
 // (zero padding of the dh2 halo outside the image makes it equal to the usual sum over p of dh2[p] * a1[p + off]),
@@ -303,6 +413,16 @@ extern "C" int wm_dwconv_fwd(const void* h1, const float* w, const float* b, voi
   if (!h1 || !w || !b || (!h2 && !a2 && !g2) || !ok(B, hw, Ch)) return WM_EINVAL;
   const int nt = hw / TP;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nt >= 8) {                                              // hw >= 64: long strips, the ring saves a fifth of the first GELUs
+    if (io_bf16)
+      hipLaunchKernelGGL(dwconv_fwd_strip_kernel<__bf16>, dim3(B * nt, Ch / TC), dim3(256), 0, st,
+                         static_cast<const __bf16*>(h1), w, b, static_cast<__bf16*>(h2), static_cast<__bf16*>(a2), static_cast<__bf16*>(g2), B, hw, Ch);
+    else
+      hipLaunchKernelGGL(dwconv_fwd_strip_kernel<float>, dim3(B * nt, Ch / TC), dim3(256), 0, st,
+                         static_cast<const float*>(h1), w, b, static_cast<float*>(h2), static_cast<float*>(a2), static_cast<float*>(g2), B, hw, Ch);
+    WM_CHECK_LAUNCH();
+    return WM_OK;
+  }
   if (io_bf16)
     hipLaunchKernelGGL(dwconv_fwd_kernel<__bf16>, dim3(B * nt * nt, Ch / TC), dim3(256), 0, st,
                        static_cast<const __bf16*>(h1), w, b, static_cast<__bf16*>(h2), static_cast<__bf16*>(a2), static_cast<__bf16*>(g2), B, hw, Ch);

@@ -197,7 +197,7 @@ def test_winattn_fwd_bwd(wm, mode, hw, C, shift):
 
 
 # ------------------------------------------------------------------------------------ dwconv
-@pytest.mark.parametrize("hw,Ch", [(16, 128), (8, 64), (32, 256)])
+@pytest.mark.parametrize("hw,Ch", [(16, 128), (8, 64), (32, 256), (64, 64), (128, 64)])   # hw >= 64: strip-walking forward
 def test_dwconv_fwd_bwd(wm, hw, Ch):
     ops = wm.ops
     B = 2
@@ -640,6 +640,18 @@ def test_elementwise_kernels_bf16_storage(wm):
     ops.dwconv_bwd(hd, dev(g).to(bf), dev(w.detach()), dh1, dwg, dbg, B, hw, Ch)
     assert_close(dh1.float(), h1.grad, 1e-2, "dwconv bwd bf16")
     assert_close(dwg, w.grad.reshape(Ch, 9), 1e-3, "dwconv dw bf16")
+    # the strip-walking forward (hw >= 64) in bf16 io: h2, gelu(h2) and gelu'(h2) against torch on the bf16-rounded input
+    hs, Cs_ = 64, 64
+    h1s = bfr(synth_array("es1", (1, hs, hs, Cs_)))
+    ws, bs = 0.3 * synth_array("esw", (Cs_, 1, 3, 3)), 0.1 * synth_array("esb", (Cs_,))
+    refs = F.conv2d(F.gelu(h1s).permute(0, 3, 1, 2), ws, bs, padding=1, groups=Cs_).permute(0, 2, 3, 1)
+    h2s = torch.empty(1, hs, hs, Cs_, device="cuda", dtype=bf)
+    a2s, g2s = torch.empty_like(h2s), torch.empty_like(h2s)
+    ops.dwconv_fwd(dev(h1s).to(bf), dev(ws), dev(bs), h2s, 1, hs, Cs_, a2=a2s, g2=g2s)
+    assert_close(h2s.float(), refs, 1e-2, "dwconv strip fwd bf16")
+    assert_close(a2s.float(), F.gelu(refs), 1e-2, "dwconv strip gelu bf16")
+    grefs = torch.autograd.functional.jvp(F.gelu, refs, torch.ones_like(refs))[1]
+    assert_close(g2s.float(), grefs, 1e-2, "dwconv strip gelu' bf16")
     # im2col / col2im / pixel (un)shuffle / strided3 / cast
     xt = synth_array("ei", (B, hw, hw, 32))
     cols32 = torch.empty(B * 64, 16 * 32, device="cuda")
