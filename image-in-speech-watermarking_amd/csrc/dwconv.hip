@@ -3,7 +3,8 @@
 // layout makes the channel dim contiguous, so no b(hw)c <-> bchw transposes are materialised.
 // Input is linear1's PRE-activation; GELU is applied once per staged element (tile + halo in LDS).
 //
-// Work split: a 256-thread workgroup owns an 8x8-pixel tile x 64 channels; a thread owns TWO channels of one tile row
+// Work split (single-tile kernels; the forward of strips of two tiles and more is dwconv_fwd_strip_kernel below): a
+// 256-thread workgroup owns an 8x8-pixel tile x 64 channels; a thread owns TWO channels of one tile row
 // (8 pixels), so the 3x3 window slides along x in registers (30 LDS reads per 8 outputs instead of 72) and every
 // multiply-add is a packed 2 x fp32 instruction.  Global traffic is 16-byte chunks, all issued before the first use
 // (the compiler does not hoist loads across LDS stores by itself), and the backward kernel walks a strip of tiles
@@ -179,20 +180,20 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ST* __restrict__ 
 // so the first GELU runs on 10 x 8 instead of 10 x 10 pixels per tile (2.25 instead of 2.56 evaluations per output with
 // the second GELU), and the next tile's columns are in flight while the current tile is computed.
 constexpr int RING = 16;
-template <typename ST> struct Cols {                          // the 8 new columns of a tile: HP rows x TP columns x 64 channels
-  static constexpr int NE = Chunk<ST>::NE, CPP = TC / NE, NCH = HP * TP * CPP, NL = (NCH + 255) / 256;
+template <typename ST, int NCOL> struct Cols {                  // NCOL pixel columns of the halo rows: HP rows x NCOL columns x 64 channels
+  static constexpr int NE = Chunk<ST>::NE, CPP = TC / NE, NCH = HP * NCOL * CPP, NL = (NCH + 255) / 256;
 };
-// columns [gx0, gx0 + ncols) of rows ty * TP - 1 .. ty * TP + TP into registers (out-of-image pixels become zero)
-template <typename ST>
-__device__ __forceinline__ void cols_load(u32x4 (&c)[Cols<ST>::NL], const ST* __restrict__ src, int b, int ty, int gx0,
+// columns [gx0, gx0 + NCOL) of rows ty * TP - 1 .. ty * TP + TP into registers (out-of-image pixels become zero)
+template <typename ST, int NCOL, int NLD>
+__device__ __forceinline__ void cols_load(u32x4 (&c)[NLD], const ST* __restrict__ src, int b, int ty, int gx0,
                                           int hw, int Ch, int cbase, int tid) {
-  typedef Cols<ST> H;
+  typedef Cols<ST, NCOL> H;
 #pragma unroll
   for (int k = 0; k < H::NL; ++k) {
     int idx = tid + 256 * k;
     idx = idx < H::NCH ? idx : H::NCH - 1;
     const int pix = idx / H::CPP, part = idx - pix * H::CPP;
-    const int ly = pix / TP, lx = pix - ly * TP;
+    const int ly = pix / NCOL, lx = pix - ly * NCOL;
     const int gy = ty * TP + ly - 1, gx = gx0 + lx;
     const bool inb = (unsigned)gy < (unsigned)hw && (unsigned)gx < (unsigned)hw;
     const int cy = min(max(gy, 0), hw - 1), cx = min(max(gx, 0), hw - 1);
@@ -202,15 +203,16 @@ __device__ __forceinline__ void cols_load(u32x4 (&c)[Cols<ST>::NL], const ST* __
   }
 }
 // gelu of the staged columns into their ring slots
-template <typename ST>
-__device__ __forceinline__ void cols_to_ring(float* ring, const u32x4 (&c)[Cols<ST>::NL], int gx0, int tid) {
-  typedef Cols<ST> H;
+template <typename ST, int NCOL, int NLD>
+__device__ __forceinline__ void cols_to_ring(float* ring, const u32x4 (&c)[NLD], int gx0, int tid) {
+  typedef Cols<ST, NCOL> H;
+  static_assert(NLD == H::NL, "register image of the columns");
 #pragma unroll
   for (int k = 0; k < H::NL; ++k) {
     const int idx = tid + 256 * k;
     if (idx < H::NCH) {
       const int pix = idx / H::CPP, part = idx - pix * H::CPP;
-      const int ly = pix / TP, lx = pix - ly * TP;
+      const int ly = pix / NCOL, lx = pix - ly * NCOL;
       float f[H::NE];
       Chunk<ST>::unpack(c[k], f);
 #pragma unroll
@@ -239,11 +241,14 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restr
   const int b = blockIdx.x / nt, ty = blockIdx.x % nt;
   const int cbase = blockIdx.y * TC;
   const int c2 = tid & 31, py = tid >> 5;
-  u32x4 creg[Cols<ST>::NL];
-  cols_load<ST>(creg, h1, b, ty, -7, hw, Ch, cbase, tid);     // columns -7 .. 0: only column 0 (and the zero column -1) matter
-  stage_weights(wl, w, bias, cbase, tid);
-  cols_to_ring<ST>(ring, creg, -7, tid);                      // zeros for the columns left of the image: gelu(0) = 0
-  cols_load<ST>(creg, h1, b, ty, 1, hw, Ch, cbase, tid);      // tile 0 adds columns 1 .. 8
+  u32x4 creg[Cols<ST, TP>::NL];
+  {
+    u32x4 c0[Cols<ST, 2>::NL];
+    cols_load<ST, 2>(c0, h1, b, ty, -1, hw, Ch, cbase, tid);  // the zero column left of the image and column 0
+    cols_load<ST, TP>(creg, h1, b, ty, 1, hw, Ch, cbase, tid);   // tile 0 adds columns 1 .. 8
+    stage_weights(wl, w, bias, cbase, tid);
+    cols_to_ring<ST, 2>(ring, c0, -1, tid);                   // gelu(0) = 0 for the padding
+  }
   __syncthreads();
   f32x2 wr[9], br;
 #pragma unroll
@@ -252,9 +257,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restr
   const int64_t strip0 = (((int64_t)b * hw + ty * TP + py) * hw) * Ch + cbase + 2 * c2;
   for (int tx = 0; tx < nt; ++tx) {
     __syncthreads();                                          // the previous tile is done with the slots about to be reused
-    cols_to_ring<ST>(ring, creg, tx * TP + 1, tid);
+    cols_to_ring<ST, TP>(ring, creg, tx * TP + 1, tid);
     __syncthreads();
-    if (tx + 1 < nt) cols_load<ST>(creg, h1, b, ty, (tx + 1) * TP + 1, hw, Ch, cbase, tid);
+    if (tx + 1 < nt) cols_load<ST, TP>(creg, h1, b, ty, (tx + 1) * TP + 1, hw, Ch, cbase, tid);
     const int s0 = tx * TP;                                   // ring slot of halo column lx: (s0 + lx) & 15
     f32x2 col[3][3];                                          // col[x % 3][dy]
 #pragma unroll
@@ -413,7 +418,7 @@ extern "C" int wm_dwconv_fwd(const void* h1, const float* w, const float* b, voi
   if (!h1 || !w || !b || (!h2 && !a2 && !g2) || !ok(B, hw, Ch)) return WM_EINVAL;
   const int nt = hw / TP;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (nt >= 8) {                                              // hw >= 64: long strips, the ring saves a fifth of the first GELUs
+  if (nt >= 2) {                                              // strips of two tiles and more: the ring saves up to a fifth of the first GELUs
     if (io_bf16)
       hipLaunchKernelGGL(dwconv_fwd_strip_kernel<__bf16>, dim3(B * nt, Ch / TC), dim3(256), 0, st,
                          static_cast<const __bf16*>(h1), w, b, static_cast<__bf16*>(h2), static_cast<__bf16*>(a2), static_cast<__bf16*>(g2), B, hw, Ch);
