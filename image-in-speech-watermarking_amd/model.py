@@ -480,16 +480,17 @@ class UformerAudio(nn.Module):
         # instead of being rebuilt in the backward pass
         return y, (pre, x, B, hw, C, w2, cols)
 
-    def _down_bwd(self, sv, dy):
+    def _down_bwd(self, sv, dy, dyh=None):
         pre, x, B, hw, C, w2, cols = sv
         G, dev, mode = self._gviews, x.device, self._mode()
         Mo = dy.shape[0]
+        dyg = dyh if dyh is not None else dy                       # GEMM operand: the bf16 copy when there is one
         dcols = self._H(dev, Mo, 16 * C)
-        ops.linear_bwd_input(dy, w2, dcols, mode)
+        ops.linear_bwd_input(dyg, w2, dcols, mode)
         dx = _E(dev, x.shape[0], C)
         ops.col2im(dcols, dx, B, hw, C)
         dw2 = _Z(dev, 2 * C, 16 * C)
-        ops.linear_bwd_weight(dy, cols, dw2, G[pre + "bias"], mode, scratch=self._gemm_scratch(dev))
+        ops.linear_bwd_weight(dyg, cols, dw2, G[pre + "bias"], mode, scratch=self._gemm_scratch(dev))
         ops.strided3(dw2, G[pre + "weight"], (2 * C, 16, C), (16 * C, C, 1), (16 * C, 1, 16), atomic=True)
         return dx
 
@@ -568,15 +569,14 @@ class UformerAudio(nn.Module):
         dyh = None                                                   # bf16 copy of dy while it comes straight out of a block
         for item in reversed(tape):
             kind = item[0]
-            if kind != "block":
-                dyh = None
             if kind == "conv2":
                 _, d2, x, z = item
                 dy = _E(x.device, *x.shape)
                 ops.conv_bwd(d2, x, P[pre + "conv2.weight"], z, dz, dy, G[pre + "conv2.weight"], G[pre + "conv2.bias"])
             elif kind == "down":
                 _, sv, i = item
-                dy = self._down_bwd(sv, dy)
+                dy = self._down_bwd(sv, dy, dyh)
+                dyh = None
                 if dfeats is not None and dfeats[i] is not None:
                     ops.axpbyz(dy, 1.0, dy, 1.0, dfeats[i], dy.numel())
             elif kind == "block":
