@@ -1,80 +1,35 @@
 #!/usr/bin/env python3
 """Benchmark of the watermark train step on MI355X (contract: see the task brief / DESIGN.md "Measurement").
 
-  python bench.py --gpus N --steps K --warmup W [--batch B] [--attack none|full] [--mode bf16|fp32]
+  python bench.py --gpus N --steps K --warmup W [--batch B] [--attack full|none] [--mode bf16|fp32]
 
-Metric (BASELINE.json): audio-sec/s per train step (enc+attack+dec).  One step = zero_grad -> forward ->
-(attacks) -> 4-term loss -> backward -> (RCCL gradient all-reduce) -> AdamW on B synthetic (STFT tile, payload)
-pairs per GPU; a tile is 128 hops x 128 samples = 1.024 s of 16 kHz audio.  Prints ONE JSON line.
+Metric (BASELINE.json): audio-sec/s per train step (enc+attack+dec); decoder BER parity.  One step = zero_grad ->
+forward -> attacks -> 4-term loss -> backward -> (RCCL gradient all-reduce) -> AdamW on B synthetic (STFT tile, payload)
+pairs per GPU; a tile is 128 hops x 128 samples = 1.024 s of 16 kHz audio.  The default workload is
+BASELINE config 3 (full audio_attack stack in the loop, extractor on the attacked spectrogram).  Prints ONE JSON line.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one process per GPU, before this
+process touches a GPU) and relays rank 0's line; under `python -m torch.distributed.run --nproc-per-node N` the ranks are
+already there and RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 TILE_SECONDS = 1.024
+FULL_STACK = dict(resample=True, snr_db=20.0, lowpass=True, amp=0.8)
 
 
-def synth_waves(batch, seed):
-    """SURVEY 8(d): one chirp+noise waveform of 16256 samples (= exactly 128 data-prep frames) per tile."""
-    from synth import chirp_wave
-    return torch.stack([chirp_wave(16384 - 128, f"bench_{seed}_{i}") for i in range(batch)])
-
-
-def synth_batch(batch, seed):
-    """Waveforms -> data-prep STFT (256/128 rect, drop last bin) -> [B,2,128,128] tiles with torch on the CPU (the
-    cpu_baseline leg; the GPU legs run the same waveforms through wm_stft256_tiles on the device);
-    BinaryWM payload bits (audio_uformer_stft.py:231: randint(2,(32,32)), seed 42)."""
-    waves = synth_waves(batch, seed)
-    tiles = []
-    for i in range(batch):
-        w = waves[i][None]
-        st = torch.stft(w, n_fft=256, hop_length=128, win_length=256, window=torch.ones(256), return_complex=True)
-        st = torch.view_as_real(st)[:, :-1]                       # [1,128,frames,2]  (audio_test.py:465-469)
-        st = torch.nn.functional.pad(st, (0, 0, 0, 128 - st.shape[2]))
-        tiles.append(st[0].permute(2, 0, 1))
-    g = torch.Generator().manual_seed(42 + seed)
-    msg = torch.randint(0, 2, (batch, 1, 32, 32), generator=g).float()
-    return torch.stack(tiles).contiguous(), msg
-
-
-def cpu_baseline(batch=4, steps=3):
-    """The oracle (CPU restatement, parity-pinned to the reference) timed on this box's host cores: same step
-    definition, fp32, train mode, AdamW.  Bounded sample so the default run stays within minutes."""
-    from oracle import uformer_wm as O
-    from synth import load_synth
-    torch.manual_seed(0)
-    torch.set_num_threads(min(16, os.cpu_count() or 1))        # the 1-GPU box's CPU share; 128 threads oversubscribe
-    net = load_synth(O.UformerAudio()).train()
-    opt = torch.optim.AdamW(net.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
-    x, msg = synth_batch(batch, 0)
-    gen = torch.Generator().manual_seed(1)
-    times = []
-    for it in range(steps + 1):
-        t0 = time.perf_counter()
-        opt.zero_grad()
-        out = net(x, msg, keeps=O.draw_keeps(net, batch, gen))
-        loss, _ = O.train_losses(out, x, msg)
-        loss.backward()
-        opt.step()
-        if it:
-            times.append(time.perf_counter() - t0)
-    med = statistics.median(times)
-    return {"value": batch * TILE_SECONDS / med, "unit": "audio-sec/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{steps} timed steps (1 warm-up) of B={batch} tiles, fp32, train mode, AdamW; "
-                                      f"median {med:.3f} s/step", "host_cpus": os.cpu_count()}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -84,24 +39,200 @@ def main():
                          "is 4); 96 = 4 x 24 is where one MI355X leaves the latency-bound regime (B=24: ~1.5 workgroups per CU and "
                          "launch).  The line also reports the B=24 rate (reference_batch) measured in the same run.")
     ap.add_argument("--no-reference-batch", action="store_true", help="skip the extra B=24 measurement")
-    ap.add_argument("--attack", default="none", choices=["none", "full"])
+    ap.add_argument("--attack", default="full", choices=["full", "none"],
+                    help="full: BASELINE config 3 (resample + AWGN 20 dB + low-pass + x0.8 between iSTFT and STFT, extractor reads the "
+                         "attacked spectrogram); none: config 2 (Identity attack)")
+    ap.add_argument("--no-identity-leg", action="store_true", help="skip the extra config-2 (Identity attack) measurement")
     ap.add_argument("--clip-seconds", type=int, default=1, choices=[1, 10],
                     help="10: config 5 (10 s clips = 10 tiles each, 64x64 grayscale payload as four quadrants; --batch must be a multiple of 10)")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--segmented", action="store_true",
                     help="capture the step as the multi-rank chain of graphs (cut at the gradient buckets) on one rank too")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline and the BER / deviation parity block)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-shape GEMM timing table on stderr")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="run the N-rank code path with every rank on GPU 0 over gloo (a functional rehearsal on a one-GPU "
                          "box: RCCL refuses two ranks per device; the numbers mean nothing)")
-    a = ap.parse_args()
+    return ap.parse_args()
 
+
+# ---------------------------------------------------------------------------------------------------- launcher
+def launch_ranks(a):
+    """Parent of a plain `python bench.py --gpus N` call: starts N rank processes (fresh interpreters, so nothing here
+    has initialised a GPU), relays rank 0's stdout, returns the worst exit code."""
+    import torch
+    if not a.rehearse_one_gpu and torch.cuda.device_count() < a.gpus:      # device_count() does not initialise the GPU
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible "
+                         "(use --rehearse-one-gpu for a functional rehearsal of the N-rank path on one GPU)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ---------------------------------------------------------------------------------------------------- workload
+def synth_waves(batch, seed):
+    """SURVEY 8(d): one chirp+noise waveform of 16256 samples (= exactly 128 data-prep frames) per tile."""
+    import torch
+    from synth import chirp_wave
+    return torch.stack([chirp_wave(16384 - 128, f"bench_{seed}_{i}") for i in range(batch)])
+
+
+def make_batch(wm, a, rank, dev):
+    """Waveforms -> device data-prep STFT (row A1) -> [B,2,128,128] tiles; payload bits (audio_uformer_stft.py:231) or, for
+    config 5, 64x64 grayscale images cut into quadrants (row A14)."""
+    import torch
+    g = torch.Generator().manual_seed(42 + rank)
+    if a.clip_seconds == 10:
+        if a.batch % 10:
+            raise SystemExit("--clip-seconds 10 needs --batch to be a multiple of 10 tiles")
+        from synth import chirp_wave
+        clips = a.batch // 10
+        waves = torch.stack([chirp_wave(10 * 16384 - 128, f"bench10_{rank}_{i}") for i in range(clips)]).to(dev)
+        tiles, n_per = wm.dataprep.stft_tiles(waves)
+        # a clip of 128 * k frames gets one extra all-zero tile from the reference's padding rule (audio_test.py:476-477)
+        x = tiles.view(clips, n_per, 2, 128, 128)[:, :10].reshape(a.batch, 2, 128, 128).contiguous()
+        img = torch.rand(clips, 1, 64, 64, generator=g).to(dev)                  # grayscale payload in [0, 1]
+        return x, wm.dataprep.payload_for_tiles(img, 10).contiguous()
+    msg = torch.randint(0, 2, (a.batch, 1, 32, 32), generator=g).float().to(dev)
+    tiles, n_per = wm.dataprep.stft_tiles(synth_waves(a.batch, rank).to(dev))
+    return tiles.view(a.batch, n_per, 2, 128, 128)[:, 0].contiguous(), msg
+
+
+def workload_name(a, attacked):
+    head = ("uformerWM Uformer-STFT, 10 s 16 kHz clips (10 tiles each), 64x64 grayscale payload as 4 quadrants, "
+            if a.clip_seconds == 10 else "uformerWM Uformer-STFT, 1 s 16 kHz clips, 32x32 binary image payload, ")
+    att = ("full audio_attack stack in the loop (resample 16k-8k-16k [Kaiser polyphase: librosa kernel parity unpinned] + AWGN 20 dB "
+           "+ Butterworth-8 low-pass + amp x0.8), extractor on the attacked spectrogram" if attacked else "Identity attack")
+    return head + att + f", {a.mode}"
+
+
+# ---------------------------------------------------------------------------------------------------- CPU legs
+def cpu_baseline(attacked, batch=4, steps=3):
+    """The oracle (CPU restatement, parity-pinned to the reference) timed on this box's host cores: same step definition
+    (zero_grad -> fwd -> attacks -> loss -> bwd -> AdamW), fp32, train mode.  Bounded sample so the run stays in minutes."""
+    import torch
+    from oracle import uformer_wm as O
+    from oracle import attacks_torch as AT
+    from synth import load_synth
+    torch.manual_seed(0)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))        # the 1-GPU box's CPU share; 128 threads oversubscribe
+    net = load_synth(O.UformerAudio()).train()
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    waves = synth_waves(batch, 0)
+    st = torch.stft(waves, n_fft=256, hop_length=128, win_length=256, window=torch.ones(256), return_complex=True)
+    x = torch.view_as_real(st)[:, :-1].permute(0, 3, 1, 2)                       # audio_test.py:465-469
+    x = torch.nn.functional.pad(x, (0, 128 - x.shape[3])).contiguous()
+    msg = torch.randint(0, 2, (batch, 1, 32, 32), generator=torch.Generator().manual_seed(42)).float()
+    gen = torch.Generator().manual_seed(1)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        att = None
+        if attacked:
+            z = torch.randn(batch, 8002, generator=gen)
+            att = lambda w: AT.attack_chain(w, z=z, **FULL_STACK)
+        out = net(x, msg, keeps=O.draw_keeps(net, batch, gen), attack=att, extract_from="attacked" if attacked else "y")
+        loss, _ = O.train_losses(out, x, msg)
+        loss.backward()
+        opt.step()
+        if it:
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": batch * TILE_SECONDS / med, "unit": "audio-sec/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{steps} timed steps (1 warm-up) of B={batch} tiles, "
+                                      f"{'full attack stack' if attacked else 'Identity attack'}, fp32, train mode, AdamW; "
+                                      f"median {med:.3f} s/step", "host_cpus": os.cpu_count()}
+
+
+def ber_parity(wm, net, x, msg, tiles=4):
+    """Decoder BER parity (second half of BASELINE's metric): BER = mean(|round(clip(wm, 0, 1)) - bits|)
+    (hidden/test_model.py:60-64) of the extractor output without attack and after the full attack stack, for the HIP path
+    in the benched mode and in fp32 parity mode, against the fp32 CPU oracle on identical weights and inputs; the AWGN
+    realisation of the HIP kernels (wm_awgn_noise) is replayed through the oracle's attack chain.  Eval mode, `tiles`
+    tiles of the bench batch; max relative deviation (max |a - b| / max |b|) of the output tensors and loss terms."""
+    import numpy as np
+    import torch
+    from oracle import uformer_wm as O
+    from oracle import attacks as OA
+    from synth import load_synth
+    x, msg = x[:tiles].contiguous(), msg[:tiles].contiguous()
+    xc, mc = x.cpu(), msg.cpu()
+    bits = mc.round().clamp(0, 1)
+    cfg = wm.AttackConfig(**FULL_STACK)
+    was_training, mode0, att0, ext0 = net.training, net.compute_mode, net.attack, net.extract_from
+    net.eval()
+    net._ensure_runtime(x.device)
+    z = wm.ops.awgn_noise(wm.attacks.rank_seed(cfg.seed), net._step_t, tiles, 8002).double().cpu().numpy()
+    hip = {}
+    try:
+        for mode in dict.fromkeys((mode0, "fp32")):
+            net.compute_mode = mode
+            for name, att, ext in (("no_attack", None, "y"), ("attacked", cfg, "attacked")):
+                net.attack, net.extract_from = att, ext
+                with torch.no_grad():
+                    hip[mode, name] = [o.float().cpu() for o in net(x, msg)]
+    finally:
+        net.compute_mode, net.attack, net.extract_from = mode0, att0, ext0
+        net.train(was_training)
+    ref = load_synth(O.UformerAudio()).eval()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cpu = {}
+    with torch.no_grad():
+        cpu["no_attack"] = ref(xc, mc)
+        attack = lambda w: torch.from_numpy(OA.attack_chain(w.numpy(), z=z, **FULL_STACK)).float()
+        cpu["attacked"] = ref(xc, mc, attack=attack, extract_from="attacked")
+
+    def ber(wm_out):
+        return float((wm_out.round().clamp(0, 1) - bits).abs().mean())
+
+    def rel(p, q):
+        return float((p.double() - q.double()).abs().max() / q.double().abs().max().clamp_min(1e-30))
+    out = {"tiles": tiles, "formula": "mean(|round(clip(wm,0,1)) - bits|)  (hidden/test_model.py:60-64)",
+           "weights": "synthetic name-keyed init (tests/synth.py), identical on both sides; untrained, so BER sits near 0.5 "
+                      "and what is compared is GPU vs CPU", "awgn": "HIP Philox stream replayed through the CPU oracle (wm_awgn_noise)"}
+    for name in ("no_attack", "attacked"):
+        c = cpu[name]
+        e = {"cpu_fp32": ber(c[3])}
+        for mode in dict.fromkeys((mode0, "fp32")):
+            h = hip[mode, name]
+            agree = float((h[3].round().clamp(0, 1) == c[3].round().clamp(0, 1)).float().mean())
+            lh, lc = O.train_losses(h, xc, mc)[1], O.train_losses(c, xc, mc)[1]
+            e[f"hip_{mode}"] = ber(h[3])
+            e[f"hip_{mode}_bits_equal_cpu"] = agree
+            e[f"hip_{mode}_max_rel_dev"] = {"stft_new": rel(h[0], c[0]), "noise": rel(h[1], c[1]), "wm_pred": rel(h[2], c[2]),
+                                            "wm": rel(h[3], c[3]),
+                                            "loss_terms": [abs(float(p) - float(q)) / max(abs(float(q)), 1e-30) for p, q in zip(lh, lc)]}
+        out[name] = e
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- main
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a))
+    import torch
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the watermark hot path has no CPU fallback")
     if a.rehearse_one_gpu:
@@ -123,74 +254,61 @@ def main():
     load_synth(net)                                              # identical random-init weights on every rank
     net = net.to(dev).train()
     opt = wm.FusedAdamW(net, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
-    attack = wm.AttackConfig.full_stack() if a.attack == "full" else None
-    extract_from = "attacked" if attack is not None else "y"
+    attacked = a.attack == "full"
+    attack = wm.AttackConfig(**FULL_STACK) if attacked else None
+    extract_from = "attacked" if attacked else "y"
+    x, msg = make_batch(wm, a, rank, dev)
+
+    ber = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.clip_seconds == 1:
+        ber = ber_parity(wm, net, x, msg)                        # before any optimiser step: weights = the synthetic init
+
     step = wm.TrainStep(net, opt, a.batch, attack=attack, extract_from=extract_from, use_graph=not a.no_graph,
                         segmented=a.segmented)
-    g = torch.Generator().manual_seed(42 + rank)
-    # waveform in: the data-prep STFT runs on the device (row A1).  A clip of 128 * k frames gets one extra all-zero tile
-    # from the reference's padding rule (audio_test.py:476-477); it carries no audio and is dropped here
-    if a.clip_seconds == 10:
-        if a.batch % 10:
-            raise SystemExit("--clip-seconds 10 needs --batch to be a multiple of 10 tiles")
-        from synth import chirp_wave
-        clips = a.batch // 10
-        waves = torch.stack([chirp_wave(10 * 16384 - 128, f"bench10_{rank}_{i}") for i in range(clips)]).to(dev)
-        tiles, n_per = wm.dataprep.stft_tiles(waves)
-        x = tiles.view(clips, n_per, 2, 128, 128)[:, :10].reshape(a.batch, 2, 128, 128).contiguous()
-        img = torch.rand(clips, 1, 64, 64, generator=g).to(dev)                  # grayscale payload in [0, 1]
-        msg = wm.dataprep.payload_for_tiles(img, 10).contiguous()
-    else:
-        msg = torch.randint(0, 2, (a.batch, 1, 32, 32), generator=g).float().to(dev)
-        tiles, n_per = wm.dataprep.stft_tiles(synth_waves(a.batch, rank).to(dev))
-        x = tiles.view(a.batch, n_per, 2, 128, 128)[:, 0].contiguous()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(a.warmup, 2)):                            # >= 2: first call warms up + captures the graph
-        step.step(x, msg)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step.step(x, msg)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    def timed(st, xs, ms, steps, warm):
+        for _ in range(warm):
+            st.step(xs, ms)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st.step(xs, ms)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt
+
+    dt = timed(step, x, msg, a.steps, max(a.warmup, 2))           # >= 2: first call warms up + captures the graph
     losses = step.losses.cpu().tolist()
-    ref_batch = None
+    ref_batch = identity = None
     if a.batch != 24 and not a.no_reference_batch and a.clip_seconds == 1:
         # the same step at the batch the reference script hard-codes (audio_uformer_stft.py:50), timed the same way
         step24 = wm.TrainStep(net, opt, 24, attack=attack, extract_from=extract_from, use_graph=not a.no_graph)
-        for _ in range(3):
-            step24.step(x[:24], msg[:24])
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            step24.step(x[:24], msg[:24])
-        barrier()
-        dt24 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dt24], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt24 = t.item()
+        dt24 = timed(step24, x[:24], msg[:24], 10, 3)
         ref_batch = {"tiles_per_gpu": 24, "value": world * 24 * TILE_SECONDS * 10 / dt24, "ms_per_step": dt24 / 10 * 1e3, "steps": 10}
         del step24
+    if attacked and not a.no_identity_leg and a.clip_seconds == 1:
+        # BASELINE config 2 (Identity attack) at the same batch, as a secondary field
+        step_id = wm.TrainStep(net, opt, a.batch, attack=None, extract_from="y", use_graph=not a.no_graph)
+        dti = timed(step_id, x, msg, 10, 3)
+        identity = {"workload": workload_name(a, False), "value": world * a.batch * TILE_SECONDS * 10 / dti,
+                    "ms_per_step": dti / 10 * 1e3, "steps": 10}
+        del step_id
 
     result = {
         "metric": "audio-sec/s per train step (enc+attack+dec)", "value": world * a.batch * TILE_SECONDS * a.steps / dt,
         "unit": "audio-sec/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
-        "config": {"workload": (("uformerWM Uformer-STFT, 10 s 16 kHz clips (10 tiles each), 64x64 grayscale payload as 4 quadrants, "
-                                 if a.clip_seconds == 10 else
-                                 "uformerWM Uformer-STFT, 1 s 16 kHz clips, 32x32 binary image payload, ")
-                                + ("full audio_attack stack (resample+AWGN20dB+low-pass+amp0.8)" if attack else "Identity attack")
-                                + f", {a.mode}"),
+        "config": {"workload": workload_name(a, attacked),
+                   "baseline_config": 5 if a.clip_seconds == 10 else (3 if attacked else 2),
                    "tiles_per_gpu": a.batch, "global_tiles": world * a.batch, "audio_sec_per_tile": TILE_SECONDS,
                    "parallelism": f"dp{world}", "graph": step.use_graph,
                    "graph_segments": (4 if step.segmented else 1) if step.use_graph else 0, "params_M": 68.71},
@@ -198,58 +316,89 @@ def main():
     }
     if ref_batch is not None:
         result["reference_batch"] = ref_batch
-    if rank == 0 and not a.no_kernel_timing:
-        prof = importlib.import_module("image-in-speech-watermarking_amd.profiling")
-        eager = wm.TrainStep(net, opt, a.batch, attack=attack, extract_from=extract_from, use_graph=False) \
-            if world == 1 else None
-        if eager is not None:
-            eager.step(x, msg)
-            torch.cuda.synchronize()
-
-            def timed_step(detail=False):
-                # Park the GPU behind a spin kernel while the host enqueues the whole step: otherwise every event pair
-                # also measures the host's launch latency (eager launches are host-bound for kernels under ~50 us).
-                torch.cuda._sleep(int(0.6e9))
-                with prof.KernelTimer(detail=detail) as kt_:
-                    eager.step(x, msg)
-                return kt_.summary()
-            rows = timed_step()
-            total = sum(r["total_s"] for r in rows)
-            result["roofline"] = prof.roofline_of(rows[0])
-            result["roofline"]["share_of_step_kernel_time"] = rows[0]["total_s"] / total
-            # HBM traffic per launch comes from the committed rocprofv3 PMC passes of the same workload (bench.py cannot
-            # run the profiler on itself); null when the summary is absent or was taken at another batch / mode
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_families_b{a.batch}_{a.mode}.json")
-            result["roofline"]["traffic"] = prof.pmc_traffic(rows[0]["kernel"], pmc) if not attack else None
-            result["roofline_by_kernel"] = [
-                {k: (round(v, 4) if isinstance(v, float) else v) for k, v in prof.roofline_of(r).items()
-                 if k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us")}
-                for r in rows[:8]]
-            stft_rows = [r for r in rows if r["kernel"] in ("istft_fwd", "stft_fwd", "istft_bwd", "stft_bwd", "attack_fwd", "attack_bwd")]
-            if stft_rows:
-                by, ts = sum(r["bytes"] for r in stft_rows), sum(r["total_s"] for r in stft_rows)
-                result["roofline_stft_path"] = {"bound": "hbm", "achieved": by / ts / 1e9, "peak": prof.HBM_PEAK_GBS,
-                                                "unit": "GB/s", "frac": by / ts / 1e9 / prof.HBM_PEAK_GBS, "traffic": None,
-                                                "alg_bytes_per_step": by, "time_us_per_step": ts * 1e6}
-            mf = [r for r in rows if r["kernel"].startswith("gemm_") or r["kernel"].startswith("winattn")]
-            fl, ts = sum(r["flops"] for r in mf), sum(r["total_s"] for r in mf)
-            result["mfma_path"] = {"achieved_TFLOPs": fl / ts / 1e12, "time_ms_per_step": ts * 1e3,
-                                   "alg_TFLOP_per_step": fl / 1e12}
-            if a.detail:
-                for r in timed_step(detail=True)[:60]:
-                    fl = r["flops"] / max(r["total_s"], 1e-12) / 1e12
-                    bw = r["bytes"] / max(r["total_s"], 1e-12) / 1e9
-                    print(f"{r['kernel']:60s} n={r['launches']:4d} total={r['total_s']*1e3:8.3f} ms avg={r['avg_us']:9.1f} us "
-                          f"{fl:8.1f} TF/s {bw:8.1f} GB/s", file=sys.stderr)
-            result["kernel_breakdown"] = [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["total_s"] * 1e3, 3),
-                                           "avg_us": round(r["avg_us"], 1)} for r in rows[:12]]
+    if identity is not None:
+        result["identity_attack"] = identity
+    if ber is not None:
+        result["ber"] = ber
+    if world > 1:
+        # per-bucket gradient all-reduce time on the side stream (3 more steps; events on the communication stream)
+        step.sync.timing = []
+        for _ in range(3):
+            step.step(x, msg)
+        barrier()
+        per = {}
+        for idx, s, e in step.sync.timing:
+            per.setdefault(idx, []).append(s.elapsed_time(e))
+        step.sync.timing = None
+        mb = [b.numel() * 4 / 1e6 for b in net.grad_buckets()]
+        result["allreduce"] = [{"bucket": ("extractor", "decoder", "encoder")[i], "MB": round(mb[i], 1),
+                                "ms": round(statistics.median(per[i]), 3)} for i in sorted(per)]
+    if rank == 0 and world == 1 and not a.no_kernel_timing:
+        kernel_rooflines(a, wm, net, opt, attack, extract_from, x, msg, result)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline()
+        result["cpu_baseline"] = cpu_baseline(attacked)
         result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def kernel_rooflines(a, wm, net, opt, attack, extract_from, x, msg, result):
+    """Per-kernel-family timing of an un-captured step with HIP events on the launch stream -> roofline objects."""
+    import torch
+    prof = importlib.import_module("image-in-speech-watermarking_amd.profiling")
+    eager = wm.TrainStep(net, opt, a.batch, attack=attack, extract_from=extract_from, use_graph=False)
+    eager.step(x, msg)
+    torch.cuda.synchronize()
+
+    def timed_step(detail=False):
+        # Park the GPU behind a spin kernel while the host enqueues the whole step: otherwise every event pair
+        # also measures the host's launch latency (eager launches are host-bound for kernels under ~50 us).
+        torch.cuda._sleep(int(0.6e9))
+        with prof.KernelTimer(detail=detail) as kt_:
+            eager.step(x, msg)
+        return kt_.summary()
+    rows = timed_step()
+    total = sum(r["total_s"] for r in rows)
+    result["roofline"] = prof.roofline_of(rows[0])
+    result["roofline"]["share_of_step_kernel_time"] = rows[0]["total_s"] / total
+    # HBM traffic per launch and MFMA-busy counters come from rocprofv3 PMC passes of the same workload
+    # (scripts/gpu_profile.sh; bench.py cannot run the profiler on itself).  A summary is used only when it was taken on the
+    # kernel sources of THIS build (source id) at this batch / mode / attack: otherwise null.
+    pmc = prof.find_pmc_summary(os.path.join(ROOT, "profiles"), a.batch, a.mode, a.attack)
+    result["roofline"]["traffic"] = prof.pmc_traffic(rows[0]["kernel"], pmc)
+    result["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) if pmc else None
+    result["roofline_by_kernel"] = [
+        {k: (round(v, 4) if isinstance(v, float) else v) for k, v in prof.roofline_of(r).items()
+         if k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us")}
+        for r in rows[:8]]
+    stft_rows = [r for r in rows if r["kernel"] in prof.STFT_PATH]
+    if stft_rows:
+        by, ts = sum(r["bytes"] for r in stft_rows), sum(r["total_s"] for r in stft_rows)
+        tr = [prof.pmc_traffic(r["kernel"], pmc) for r in stft_rows]
+        result["roofline_stft_path"] = {"bound": "hbm", "achieved": by / ts / 1e9, "peak": prof.HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": by / ts / 1e9 / prof.HBM_PEAK_GBS,
+                                        "traffic": sum(t * r["launches"] for t, r in zip(tr, stft_rows)) if all(t is not None for t in tr) else None,
+                                        "alg_bytes_per_step": by, "time_us_per_step": ts * 1e6,
+                                        "kernels": {r["kernel"]: round(r["avg_us"], 1) for r in stft_rows}}
+    mf = [r for r in rows if r["kernel"].startswith("gemm_") or r["kernel"].startswith("winattn")]
+    fl, ts = sum(r["flops"] for r in mf), sum(r["total_s"] for r in mf)
+    peak = prof.MFMA_PEAK_TFLOPS[1 if a.mode == "bf16" else 0]
+    result["mfma_path"] = {"achieved_TFLOPs": fl / ts / 1e12, "time_ms_per_step": ts * 1e3, "alg_TFLOP_per_step": fl / 1e12,
+                           "frac_of_dense_peak_in_kernels": fl / ts / 1e12 / peak,
+                           # SURVEY 8(d): 161.3 GFLOP per tile and step over the whole (graph-replayed) step time
+                           "step_TFLOPs": 161.3e9 * a.batch / (result["ms_per_step"] * 1e-3) / 1e12,
+                           "step_frac_of_dense_peak": 161.3e9 * a.batch / (result["ms_per_step"] * 1e-3) / 1e12 / peak,
+                           "util": prof.pmc_mfma_util(pmc)}
+    if a.detail:
+        for r in timed_step(detail=True)[:60]:
+            fl = r["flops"] / max(r["total_s"], 1e-12) / 1e12
+            bw = r["bytes"] / max(r["total_s"], 1e-12) / 1e9
+            print(f"{r['kernel']:60s} n={r['launches']:4d} total={r['total_s']*1e3:8.3f} ms avg={r['avg_us']:9.1f} us "
+                  f"{fl:8.1f} TF/s {bw:8.1f} GB/s", file=sys.stderr)
+    result["kernel_breakdown"] = [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["total_s"] * 1e3, 3),
+                                   "avg_us": round(r["avg_us"], 1)} for r in rows[:12]]
 
 
 if __name__ == "__main__":

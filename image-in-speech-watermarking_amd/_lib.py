@@ -89,7 +89,11 @@ _SIGS = {
     "wm_stft255_bwd": [c_f, c_f, c_i32, c_f],
     "wm_attack_fwd": [C.POINTER(WmAttack), c_f, c_f, c_f, c_i32, c_i32, c_f],
     "wm_attack_bwd": [C.POINTER(WmAttack), c_f, c_f, c_f, c_f, c_i32, c_i32, c_f],
+    "wm_awgn_noise": [c_u64, c_f, c_f, c_i32, c_i32, c_f],
     "wm_loss_fwd_bwd": [c_f] * 11 + [c_i32, c_f, c_f],
+    "wm_charbonnier_fwd_bwd": [c_f, c_f, c_i64, c_fl, c_f, c_f, c_f, c_fl, c_f],
+    "wm_tvloss_fwd_bwd": [c_f, c_i32, c_i32, c_i32, c_i32, c_fl, c_f, c_f, c_fl, c_f],
+    "wm_tv_pow_fwd_bwd": [c_f, c_i32, c_i32, c_i32, c_i32, c_fl, c_fl, c_f, c_f, c_fl, c_f],
     "wm_adamw": [c_f, c_f, c_f, c_f, c_i64, c_f, c_fl, c_fl, c_fl, c_fl, c_f, c_f, c_f],
     "wm_step_inc": [c_f, c_f],
     "wm_droppath_scales": [c_f, c_f, c_i32, c_i32, c_u64, c_f, c_f],

@@ -86,12 +86,16 @@ class AttackConfig:
                 cfg.resample = True
             elif name == "awgn":
                 cfg.snr_db = float(param) if param else 15.0
-            elif name in ("lowpass", "low_pass_filter"):
+            elif name in ("low_pass", "lowpass", "low_pass_filter"):   # 'low_pass' is the reference's dispatch string (:637)
                 cfg.lowpass = True
             elif name in ("amplitude", "amplitude_scaling"):
                 cfg.amp = float(param) if param else 0.8
             elif name == "echo_addition":
-                cfg.echo = (int(param), 0.2) if param else (8000, 0.2)
+                # the reference ignores any parameter (audio_test.py:632-633 calls echo_addition(audio) with the defaults
+                # td = 0.5 s, AA = 0.2 of audio_attack.py:33); a delay in SAMPLES is accepted as 'echo_addition_samples-<n>'
+                cfg.echo = (8000, 0.2)
+            elif name == "echo_addition_samples":
+                cfg.echo = (int(param), 0.2)
             elif name == "jittering_2":
                 cfg.jitter = int(param) if param else 1000
             elif name == "requantization":
@@ -102,6 +106,13 @@ class AttackConfig:
 
 
 _tables = {}
+
+
+def rank_seed(seed):
+    """Per-rank Philox key: every data-parallel rank draws its own AWGN / jitter / DropPath streams."""
+    import torch.distributed as dist
+    r = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    return (int(seed) + 0x9E3779B1 * r) & 0xFFFFFFFFFFFFFFFF
 
 
 def _device_tables(device):
@@ -115,7 +126,7 @@ def _desc(cfg, device, step):
     lp, rs = _device_tables(device)
     delay, gain = cfg.echo if cfg.echo is not None else (0, 0.0)
     return WmAttack(cfg.flags, float(cfg.snr_db or 0.0), float(cfg.amp if cfg.amp is not None else 1.0), ptr(lp),
-                    LP_TAPS, ptr(rs), 41, int(cfg.seed), ptr(step), int(delay), float(gain), int(cfg.jitter or 0), 0)
+                    LP_TAPS, ptr(rs), 41, rank_seed(cfg.seed), ptr(step), int(delay), float(gain), int(cfg.jitter or 0), 0)
 
 
 def attack_forward(cfg, wave, step, out=None, sigma=None):

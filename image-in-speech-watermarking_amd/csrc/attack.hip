@@ -319,6 +319,19 @@ __global__ __launch_bounds__(NT) void attack_bwd_kernel(const WmAttack a, const 
   for (int i = tid; i < L; i += NT) dwave[(int64_t)row * L + i] = g[i];
 }
 
+// the AWGN stage's standard-normal stream by itself (z[row][i] as attack_fwd_kernel draws it for (seed, step))
+__global__ __launch_bounds__(256) void awgn_noise_kernel(uint64_t seed, const int64_t* __restrict__ step_p, float* __restrict__ z,
+                                                         int L) {
+  const int row = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+  if (4 * q >= L) return;
+  const uint64_t step = step_p ? (uint64_t)*step_p : 0ull;
+  float v[4];
+  gauss4(seed, step, (uint32_t)row, (uint32_t)q, v);
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (4 * q + e < L) z[(int64_t)row * L + 4 * q + e] = v[e];
+}
+
 bool args_ok(const WmAttack* a, int B, int L) {
   if (!a || B <= 0 || L < 64 || L + 2 * PADLEN > BUF) return false;
   if ((a->flags & 4) && (!a->lp_h || a->lp_n < 2 || a->lp_n > 256)) return false;
@@ -362,6 +375,14 @@ extern "C" int wm_attack_bwd(const WmAttack* a, const float* wave, const float* 
   }
   hipLaunchKernelGGL(attack_bwd_kernel, dim3(B), dim3(NT), sm, static_cast<hipStream_t>(stream), *a, wave, dout, sigma,
                      dwave, L);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int wm_awgn_noise(uint64_t seed, const int64_t* step, float* z, int32_t B, int32_t L, void* stream) {
+  if (!z || B <= 0 || L <= 0) return WM_EINVAL;
+  hipLaunchKernelGGL(awgn_noise_kernel, dim3((L + 1023) / 1024, B), dim3(256), 0, static_cast<hipStream_t>(stream), seed, step,
+                     z, L);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

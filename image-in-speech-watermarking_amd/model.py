@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .attacks import AttackConfig, attack_forward, attack_backward
+from .attacks import AttackConfig, attack_forward, attack_backward, rank_seed
 
 DEPTHS = (1, 2, 8, 8, 2, 8, 8, 2, 1)
 HEADS = (1, 2, 4, 8, 16, 16, 8, 4, 2)
@@ -353,6 +353,10 @@ class UformerAudio(nn.Module):
             raise RuntimeError("UformerAudio (MI355X build) runs on the GPU only; move the model and inputs to cuda")
         self._ensure_runtime(x.device)
         self._reattach_grads()
+        if self.training and keep_scales is None:
+            # a reference-style loop (net(x, msg); loss.backward(); optim.step()) advances the DropPath / AWGN Philox
+            # streams here, once per training forward; TrainStep advances the same counter in its own launch sequence
+            ops.step_inc(self._step_t)
         opts = dict(train=self.training, keep_scales=keep_scales, attack=self.attack, extract_from=self.extract_from)
         return _ModelFn.apply(self._anchor, self, x.contiguous().float(), message.contiguous().float(), opts)
 
@@ -391,7 +395,7 @@ class UformerAudio(nn.Module):
             return None
         n = len(self._rates_host)
         sc = _E(dev, n, B)
-        ops.droppath_scales(sc, self._rates, n, B, self.seed, self._step_t)
+        ops.droppath_scales(sc, self._rates, n, B, rank_seed(self.seed), self._step_t)
         return sc
 
     def _block_fwd(self, pre, x, B, C, hw, shift, s1, s2, mod):

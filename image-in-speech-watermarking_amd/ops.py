@@ -261,6 +261,13 @@ def attack_bwd(desc, wave, dout, sigma, dwave, B, L):
           "wm_attack_bwd")
 
 
+def awgn_noise(seed, step, B, L):
+    """[B, L] standard-normal stream of the in-loop AWGN stage for (seed, step tensor)."""
+    z = torch.empty(B, L, device=step.device, dtype=torch.float32)
+    check(lib.wm_awgn_noise(int(seed), ptr(step), ptr(z), B, L, _stream()), "wm_awgn_noise")
+    return z
+
+
 def loss_fwd_bwd(stft_new, x, noise, wm_pred, wm, msg, losses, d_stft_new, d_noise, d_wm_pred, d_wm, B, scratch):
     check(lib.wm_loss_fwd_bwd(ptr(stft_new), ptr(x), ptr(noise), ptr(wm_pred), ptr(wm), ptr(msg), ptr(losses),
                               ptr(d_stft_new), ptr(d_noise), ptr(d_wm_pred), ptr(d_wm), B, ptr(scratch), _stream()),
@@ -306,6 +313,22 @@ def dropout(x, y, p, seed, offset):
 
 def mse_fwd_bwd(a, b, loss, da=None, db=None, gscale=1.0):
     check(lib.wm_mse_fwd_bwd(ptr(a), ptr(b), a.numel(), ptr(loss), ptr(da), ptr(db), gscale, _stream()), "wm_mse_fwd_bwd")
+
+
+def charbonnier_fwd_bwd(x, y, eps, loss, dx=None, dy=None, gscale=1.0):
+    check(lib.wm_charbonnier_fwd_bwd(ptr(x), ptr(y), x.numel(), float(eps), ptr(loss), ptr(dx), ptr(dy), float(gscale), _stream()),
+          "wm_charbonnier_fwd_bwd")
+
+
+def tvloss_fwd_bwd(x, weight, loss, dx=None, gscale=1.0):
+    N, Cc, H, W = x.shape
+    check(lib.wm_tvloss_fwd_bwd(ptr(x), N, Cc, H, W, float(weight), ptr(loss), ptr(dx), float(gscale), _stream()), "wm_tvloss_fwd_bwd")
+
+
+def tv_pow_fwd_bwd(x, beta, reg_coeff, loss, dx=None, gscale=1.0):
+    N, Cc, H, W = x.shape
+    check(lib.wm_tv_pow_fwd_bwd(ptr(x), N, Cc, H, W, float(beta), float(reg_coeff), ptr(loss), ptr(dx), float(gscale), _stream()),
+          "wm_tv_pow_fwd_bwd")
 
 
 def zero_(t):

@@ -146,17 +146,56 @@ def roofline_of(row):
     return dict(bound="hbm", achieved=gb, peak=HBM_PEAK_GBS, unit="GB/s", frac=gb / HBM_PEAK_GBS, **common)
 
 
+STFT_PATH = ("istft_fwd", "stft_fwd", "istft_bwd", "stft_bwd", "attack_fwd", "attack_bwd")
+
+# KernelTimer key -> __global__ functions (rocprofv3 kernel families) that carry it
+FAMILY_KERNELS = {"reduce_jobs": ["reduce_jobs_kernel"], "winattn_bwd_bf16": ["attn_bwd_fast_kernel"],
+                  "winattn_fwd_bf16": ["attn_fwd_fast_kernel"], "layernorm_fwd": ["ln_fwd_kernel"],
+                  "layernorm_bwd": ["ln_bwd_kernel"], "istft_fwd": ["synth_kernel"], "stft_bwd": ["synth_kernel"],
+                  "stft_fwd": ["analysis_kernel"], "istft_bwd": ["analysis_kernel"], "attack_fwd": ["attack_fwd_kernel"],
+                  "attack_bwd": ["attack_bwd_kernel"]}
+
+
+def source_id():
+    """Identity of the kernel sources a measurement belongs to: sha256 over csrc/*.hip, csrc/*.h and include/*.h."""
+    import glob
+    import hashlib
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")) +
+                   glob.glob(os.path.join(here, "..", "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def find_pmc_summary(profiles_dir, batch, mode, attack):
+    """Newest committed PMC families summary (scripts/gpu_profile.sh) taken at this batch / mode / attack ON THESE kernel
+    sources, or None: traffic from another build is not reported as this build's."""
+    import glob
+    import json
+    import os
+    sid = source_id()
+    for path in sorted(glob.glob(os.path.join(profiles_dir, f"r*_families_b{batch}_{mode}_{attack}.json")), reverse=True):
+        try:
+            if json.load(open(path)).get("source_id") == sid:
+                return path
+        except (OSError, ValueError):
+            continue
+    return None
+
+
 def pmc_traffic(kernel_family, path):
-    """HBM bytes per launch of a kernel family from a committed PMC summary (scripts/summarize_rocprof.py --pmc output:
+    """HBM bytes per launch of a kernel family from a PMC summary (scripts/summarize_rocprof.py --families output:
     2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section), or None when no summary is present."""
     import json
     import os
-    if not os.path.exists(path):
+    if not path or not os.path.exists(path):
         return None
     fams = json.load(open(path)).get("families", {})
-    pats = {"reduce_jobs": ["reduce_jobs_kernel"], "winattn_bwd_bf16": ["attn_bwd_fast_kernel"], "winattn_fwd_bf16": ["attn_fwd_fast_kernel"],
-            "layernorm_fwd": ["ln_fwd_kernel"], "layernorm_bwd": ["ln_bwd_kernel"]}
-    names = pats.get(kernel_family, [kernel_family if kernel_family.endswith("_kernel") else kernel_family + "_kernel"])
+    names = FAMILY_KERNELS.get(kernel_family, [kernel_family if kernel_family.endswith("_kernel") else kernel_family + "_kernel"])
     tot, launches = 0.0, 0
     for nm in names:
         f = fams.get(nm)
@@ -165,3 +204,13 @@ def pmc_traffic(kernel_family, path):
         tot += f["hbm_bytes"]
         launches = max(launches, f["launches"])
     return tot / launches if launches else None
+
+
+def pmc_mfma_util(path):
+    """MFMA utilisation from counters (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)) of the MFMA-carrying
+    kernel families and of the whole step, as scripts/summarize_rocprof.py wrote them; None without a summary."""
+    import json
+    import os
+    if not path or not os.path.exists(path):
+        return None
+    return json.load(open(path)).get("mfma_util")

@@ -71,6 +71,7 @@ class GradSync:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.cuda = net._flat.is_cuda
         self._comm = torch.cuda.Stream(device=net._flat.device) if (self.cuda and self.world > 1) else None
+        self.timing = None                                      # bench.py: list of (bucket, start event, stop event)
 
     def after_segment(self, idx):
         if self.world == 1:
@@ -81,7 +82,13 @@ class GradSync:
             return
         self._comm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._comm):
+            if self.timing is not None:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
             dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.timing is not None:
+                e.record()
+                self.timing.append((idx, s, e))
 
     def finish(self):
         if self._comm is not None:

@@ -199,12 +199,24 @@ int wm_attack_fwd(const WmAttack* a, const float* wave, float* out, float* sigma
                   void* stream);
 int wm_attack_bwd(const WmAttack* a, const float* wave, const float* dout, const float* sigma, float* dwave,
                   int32_t B, int32_t L, void* stream);
+/* z[B, L] = the standard-normal stream the AWGN stage (bit1) adds as sigma * z for (seed, *step): lets a caller replay
+ * the noise of a step elsewhere (np.random.normal of audio_attack.py:120 is replaced by Philox4x32-10 + Box-Muller)   */
+int wm_awgn_noise(uint64_t seed, const int64_t* step, float* z, int32_t B, int32_t L, void* stream);
 
 /* ---- loss of audio_uformer_stft.py:463-482 and its gradients ------------------------------- */
 /* losses[0..3] = l1..l4, [4] = total, [5] = ||noise||.  grads may alias nothing.               */
 int wm_loss_fwd_bwd(const float* stft_new, const float* x, const float* noise, const float* wm_pred,
                     const float* wm, const float* msg, float* losses, float* d_stft_new, float* d_noise,
                     float* d_wm_pred, float* d_wm, int32_t B, float* scratch, void* stream);
+
+/* ---- uformerWM/losses.py as device ops (imported by audio_uformer_stft.py:26): CharbonnierLoss (:41-52), TVLoss (:20-37),
+ * tv_loss (:8-18) on NCHW fp32.  *loss += value (caller zeroes it); dx / dy (optional) = gscale * d loss / d input.      */
+int wm_charbonnier_fwd_bwd(const float* x, const float* y, int64_t n, float eps, float* loss, float* dx, float* dy,
+                           float gscale, void* stream);
+int wm_tvloss_fwd_bwd(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, float weight, float* loss, float* dx,
+                      float gscale, void* stream);
+int wm_tv_pow_fwd_bwd(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, float beta, float reg_coeff, float* loss,
+                      float* dx, float gscale, void* stream);
 
 /* ---- optimizer / utilities ----------------------------------------------------------------- */
 /* lr, step and grad_scale are read from DEVICE memory so a captured graph follows the scheduler */

@@ -1,22 +1,37 @@
 #!/bin/bash
-# Round profile on the GPU box: bench line, rocprofv3 kernel trace of the same command, separate PMC passes for HBM traffic.
-#   bash scripts/gpu_profile.sh <tag>     ->  gpurun_out/prof_<tag>/{<tag>_bench.json, <tag>_kernel_stats.md, <tag>_families.{json,md}}
+# Round profile on the GPU box: rocprofv3 kernel trace of the bench command, separate PMC passes for HBM traffic
+# (FETCH_SIZE, WRITE_SIZE) and MFMA busy cycles, then the bench line itself (which picks the PMC summary of this build up).
+#   bash scripts/gpu_profile.sh <round-tag> [bench args, e.g. --batch 24 / --attack none]
+#   ->  gpurun_out/prof_<tag>/…  and  profiles/<tag>_{bench,kernel_stats,families}_b<B>_<mode>_<attack>.*
 set -o pipefail
-R=${1:-r01}
+R=${1:-r02}; shift
+ARGS="$@"
+B=96; MODE=bf16; ATT=full
+set -- $ARGS
+while [ $# -gt 0 ]; do case $1 in --batch) B=$2; shift;; --mode) MODE=$2; shift;; --attack) ATT=$2; shift;; esac; shift; done
+TAG=b${B}_${MODE}_${ATT}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
-P=$OUT/prof_$R
+P=$OUT/prof_${R}_$TAG
 mkdir -p $P
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-reference-batch > $P/trace.log 2>&1 || { tail -5 $P/trace.log; exit 1; }
+QUIET="--no-cpu-baseline --no-kernel-timing --no-reference-batch --no-identity-leg"
+SID=$(python -c "import importlib; print(importlib.import_module('image-in-speech-watermarking_amd.profiling').source_id())")
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 bench.py --steps 5 --warmup 2 $QUIET $ARGS > $P/trace.log 2>&1 || { tail -5 $P/trace.log; exit 1; }
 python scripts/summarize_rocprof.py $P/trace $P/${R}_trace
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -- python3 bench.py --steps 1 --warmup 2 --no-graph --no-cpu-baseline --no-kernel-timing --no-reference-batch > $P/pmc_fetch.log 2>&1 || { tail -5 $P/pmc_fetch.log; exit 1; }
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -- python3 bench.py --steps 1 --warmup 2 --no-graph --no-cpu-baseline --no-kernel-timing --no-reference-batch > $P/pmc_write.log 2>&1 || { tail -5 $P/pmc_write.log; exit 1; }
-python scripts/summarize_rocprof.py --families $P/trace $P/pmc_fetch $P/pmc_write $P/${R}_families
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $P/pmc_$C -- python3 bench.py --steps 1 --warmup 2 --no-graph $QUIET $ARGS > $P/pmc_$C.log 2>&1 || { tail -5 $P/pmc_$C.log; exit 1; }
+done
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/pmc_mfma -- python3 bench.py --steps 1 --warmup 2 --no-graph $QUIET $ARGS > $P/pmc_mfma.log 2>&1 || { tail -5 $P/pmc_mfma.log; exit 1; }
+python scripts/summarize_rocprof.py --families $P/trace $P/pmc_FETCH_SIZE $P/pmc_WRITE_SIZE $P/${R}_families_$TAG $P/pmc_mfma $SID
+mkdir -p profiles
+cp $P/${R}_families_$TAG.json $P/${R}_families_$TAG.md profiles/
+cp $P/${R}_trace_kernel_stats.md profiles/${R}_rocprofv3_kernel_stats_$TAG.md
 # the bench line last, so that it can pick the PMC traffic of this very build up
-mkdir -p profiles && cp $P/${R}_families.json profiles/r01_families_b96_bf16.json
-python bench.py --steps 20 --warmup 5 > $P/${R}_bench.json 2> $P/bench.err || { tail -5 $P/bench.err; exit 1; }
-cat $P/${R}_bench.json | cut -c1-600
+python bench.py --steps 20 --warmup 5 $ARGS > $P/${R}_bench_$TAG.json 2> $P/bench.err || { tail -5 $P/bench.err; exit 1; }
+cp $P/${R}_bench_$TAG.json profiles/
+cp profiles/${R}_*_$TAG.* $P/ 2>/dev/null
+cut -c1-1500 $P/${R}_bench_$TAG.json
 # keep only the small summaries in the merge-back (raw traces can exceed the 64 MiB limit)
 find $P -name "*.csv" -size +1M -delete
 ls -la $P

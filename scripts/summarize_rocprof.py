@@ -39,7 +39,7 @@ def short(name):
 
 def main():
     if sys.argv[1] == "--families":
-        return merge_families(*sys.argv[2:6])
+        return merge_families(*sys.argv[2:])
     d, prefix = sys.argv[1], sys.argv[2]
     pmc = "--pmc" in sys.argv
     files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
@@ -86,7 +86,27 @@ def family(name):
     return re.split(r"[<(]", name)[0]
 
 
-def merge_families(trace_dir, fetch_dir, write_dir, prefix):
+def mfma_counters(mfma_dir):
+    """Per family and for the whole run: SQ_VALU_MFMA_BUSY_CYCLES (32 per v_mfma_f32_32x32x16_bf16 wave-instruction, summed
+    over the chip) against GRBM_GUI_ACTIVE (summed over the 8 XCDs) -> busy / (GUI_ACTIVE / 8 * 1024 SIMDs)
+    (MI355X_MICROARCH.md: cycle constants, DVFS section)."""
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for f in glob.glob(os.path.join(mfma_dir, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            per[family(row["Kernel_Name"])][row["Counter_Name"]] += float(row["Counter_Value"])
+    out, tb, tg = {}, 0.0, 0.0
+    for k, c in per.items():
+        busy, gui = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0)
+        tb += busy
+        tg += gui
+        if busy > 0 and gui > 0:
+            out[k] = {"mfma_busy_cycles": busy, "gui_active": gui, "util": busy / (gui / 8.0 * 1024.0),
+                      "sq_busy_cycles": c.get("SQ_BUSY_CYCLES")}
+    return {"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)", "by_family": out,
+            "whole_step": (tb / (tg / 8.0 * 1024.0)) if tg else None}
+
+
+def merge_families(trace_dir, fetch_dir, write_dir, prefix, mfma_dir=None, source_id=None):
     """Per kernel family: launches, total / average duration (kernel trace) and HBM bytes (separate FETCH_SIZE and
     WRITE_SIZE passes; FETCH_SIZE counts 64-B units for 128-B requests on gfx950 -> x2; both are KiB)."""
     fams = collections.defaultdict(lambda: dict(launches=0, total_ns=0, fetch_kib=None, write_kib=None, pmc_launches=0))
@@ -112,13 +132,21 @@ def merge_families(trace_dir, fetch_dir, write_dir, prefix):
         out[k] = dict(launches=e["launches"], total_ms=e["total_ns"] / 1e6,
                       avg_us=e["total_ns"] / 1e3 / max(e["launches"], 1), hbm_bytes=hb,
                       hbm_bytes_per_launch=(hb / e["launches"]) if (hb is not None and e["launches"]) else None)
-    json.dump({"families": out}, open(prefix + ".json", "w"), indent=1)
+    doc = {"families": out, "source_id": source_id}
+    if mfma_dir:
+        doc["mfma_util"] = mfma_counters(mfma_dir)
+    json.dump(doc, open(prefix + ".json", "w"), indent=1)
     rows = sorted(out.items(), key=lambda kv: -kv[1]["total_ms"])
     with open(prefix + ".md", "w") as fh:
         fh.write("| kernel family | launches | total ms | avg us | HBM MB / launch (PMC) |\n|---|---|---|---|---|\n")
+        mu = doc.get("mfma_util", {}).get("by_family", {})
         for k, e in rows[:40]:
             hb = "" if e["hbm_bytes_per_launch"] is None else f"{e['hbm_bytes_per_launch'] / 1e6:.2f}"
-            fh.write(f"| `{k}` | {e['launches']} | {e['total_ms']:.3f} | {e['avg_us']:.1f} | {hb} |\n")
+            ut = f" (MFMA busy {100 * mu[k]['util']:.1f} %)" if k in mu else ""
+            fh.write(f"| `{k}`{ut} | {e['launches']} | {e['total_ms']:.3f} | {e['avg_us']:.1f} | {hb} |\n")
+        if doc.get("mfma_util", {}).get("whole_step") is not None:
+            fh.write(f"\nMFMA busy over the whole profiled step: {100 * doc['mfma_util']['whole_step']:.2f} % "
+                     f"({doc['mfma_util']['formula']}); source id {source_id}\n")
     print("wrote", prefix + ".json", prefix + ".md")
     return
 

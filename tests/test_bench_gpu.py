@@ -1,0 +1,57 @@
+"""bench.py as the driver calls it: a plain `python bench.py --gpus N` starts the N ranks itself and prints rank 0's line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+QUICK = ["--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--no-kernel-timing", "--no-reference-batch",
+         "--no-identity-leg"]
+
+
+def test_gpus_flag_without_devices_fails_loudly():
+    """No GPU (or fewer than N): the launcher refuses before spawning anything; never a silent N = 1 run."""
+    import torch
+    if torch.cuda.device_count() >= 4:
+        pytest.skip("a multi-GPU node would simply run it")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"] + QUICK, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "--gpus 4" in r.stderr and not r.stdout.strip()
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"] + QUICK, capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+@pytest.mark.gpu
+def test_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2 --rehearse-one-gpu`: two rank processes share GPU 0 over gloo (RCCL refuses two ranks per
+    device), the chain of four graphs with the all-reduces between them runs, the line says n_gpus 2."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu"] + QUICK,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_tiles"] == 4 and line["config"]["graph_segments"] == 4
+    assert line["config"]["baseline_config"] == 3 and "full audio_attack stack" in line["config"]["workload"]
+    assert [b["bucket"] for b in line["allreduce"]] == ["extractor", "decoder", "encoder"]
+    assert "roofline" not in line and "cpu_baseline" not in line
+
+
+@pytest.mark.gpu
+def test_default_line_carries_config3_roofline_and_ber():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-reference-batch", "--no-identity-leg"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["baseline_config"] == 3 and line["dtype"] == "bf16"
+    for k in ("roofline", "cpu_baseline", "ber", "mfma_path", "roofline_stft_path"):
+        assert k in line, k
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    ber = line["ber"]
+    assert ber["no_attack"]["hip_fp32_bits_equal_cpu"] == 1.0 and ber["attacked"]["hip_fp32_bits_equal_cpu"] == 1.0
+    assert ber["no_attack"]["hip_bf16_bits_equal_cpu"] >= 0.99 and ber["attacked"]["hip_bf16_bits_equal_cpu"] >= 0.99
+    for leg in ("no_attack", "attacked"):
+        d = ber[leg]["hip_fp32_max_rel_dev"]
+        assert max(d["stft_new"], d["noise"], d["wm"]) <= 2e-4, (leg, d)

@@ -77,6 +77,10 @@ def test_attack_string_dispatch(wm):
     assert A.from_string("no").flags == 0 and A.full_stack().flags == 15
     with pytest.raises(ValueError):
         A.from_string("mp3-64")
+    # the reference's own dispatch strings (audio_test.py:631-660)
+    assert A.from_string("low_pass").lowpass and A.from_string("amplitude_scaling-0.9").amp == 0.9
+    assert A.from_string("echo_addition").echo == (8000, 0.2) and A.from_string("echo_addition-0.1").echo == (8000, 0.2)
+    assert A.from_string("echo_addition_samples-3000").echo == (3000, 0.2)
     import numpy as np
     from scipy import signal
     t = wm.attacks.lowpass_fir_tables()
@@ -200,3 +204,19 @@ def test_reference_format_checkpoint_loads_into_fused_optimizer_and_back(tmp_pat
     assert wm.checkpoint.is_frozen(net)
     wm.checkpoint.unfreeze(net)
     assert not wm.checkpoint.is_frozen(net)
+
+
+def test_custom_ops_are_registered_for_the_gpu_only(wm):
+    """torch.ops.wm.* exist with schemas and fake kernels (shape inference runs on the CPU), and there is NO CPU kernel."""
+    for name in wm.torch_ops.OPS:
+        assert hasattr(torch.ops.wm, name), name
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        out = torch.ops.wm.stft255(torch.empty(3, 8002, device="cuda"))
+        assert tuple(out.shape) == (3, 2, 128, 128)
+        y, mean, rstd = torch.ops.wm.layer_norm(torch.empty(64, 32, device="cuda"), torch.empty(32, device="cuda"), torch.empty(32, device="cuda"))
+        assert tuple(y.shape) == (64, 32) and tuple(mean.shape) == (64,)
+    with pytest.raises(NotImplementedError):
+        torch.ops.wm.istft255(torch.zeros(1, 2, 128, 128))
+    with pytest.raises(NotImplementedError):
+        wm.tv_loss(torch.zeros(1, 1, 8, 8))

@@ -245,3 +245,197 @@ def test_resume_from_reference_format_checkpoint(wm, tmp_path):
         bad += int((d > 1e-4 * v.double().abs() + 5e-6).sum())
         total += v.numel()
     assert bad <= 1e-2 * total, (bad, total)                   # (a wrong moment mapping moves every element)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 2: the benched mode (bf16) and the benched configurations (3 and 5) against the oracle
+# ------------------------------------------------------------------------------------------------------------------
+def _record(name, payload):
+    """Measured deviations go to gpurun_out/ (merged back from the GPU box; the judged copies live under profiles/)."""
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name), "w") as fh:
+            json.dump(payload, fh, indent=1)
+    except OSError:
+        pass
+
+
+def _bucket_names(net):
+    a, b, c = net._seg_sizes[:3]
+    return (("encoder+payload AE", 0, a), ("decoder", a, a + b), ("extractor", a + b, a + b + c))
+
+
+def test_bf16_train_step_gradients_against_fp32_mode(wm):
+    """The benched path: one un-captured TrainStep in bf16 mode and one in fp32 parity mode from the same weights
+    (drop_path_rate = 0): loss terms and every gradient bucket of the flat arena, norm-wise."""
+    x, msg = synth_tile(2, "bf_x").cuda(), synth_bits("bf_msg", (2, 1, 32, 32)).cuda()
+    grads, losses = {}, {}
+    for mode in ("fp32", "bf16"):
+        m = wm.UformerAudio(modulator=True, drop_path_rate=0.0, compute_mode=mode)
+        load_synth(m)
+        m = m.cuda().train()
+        st = wm.TrainStep(m, wm.FusedAdamW(m, lr=0.0, weight_decay=0.0), 2, use_graph=False)
+        st.step(x, msg)
+        torch.cuda.synchronize()
+        grads[mode], losses[mode] = m._flat_grad.double().cpu(), st.losses.double().cpu()
+        names = _bucket_names(m)
+    rec = {"loss_terms_rel": ((losses["bf16"][:5] - losses["fp32"][:5]).abs() / losses["fp32"][:5].abs()).tolist(), "buckets": {}}
+    for name, lo, hi in names:
+        a, b = grads["bf16"][lo:hi], grads["fp32"][lo:hi]
+        rec["buckets"][name] = {"norm_rel_err": ((a - b).norm() / b.norm()).item(), "cosine": (a @ b / (a.norm() * b.norm())).item()}
+    _record("r02_parity_bf16_trainstep_b2.json", rec)
+    assert max(rec["loss_terms_rel"]) <= 2e-2, rec
+    for name, e in rec["buckets"].items():
+        assert e["norm_rel_err"] <= 6e-2 and e["cosine"] >= 0.998, (name, e)
+
+
+def test_bf16_whole_model_b6_against_cpu_oracle(wm):
+    """bf16 mode at B = 6 — enough rows for the 128x128 and N = 192 GEMM instances and the multi-tile strip kernels the
+    bench uses — eval forward and train-mode (drop_path_rate = 0) gradients against the fp32 CPU oracle on the same
+    weights; deviations and BER are recorded (profiles/r02_parity_bf16_b6.json is the committed copy)."""
+    B = 6
+    x, msg = synth_tile(B, "b6_x"), synth_bits("b6_msg", (B, 1, 32, 32))
+    m = wm.UformerAudio(modulator=True, drop_path_rate=0.0, compute_mode="bf16")
+    load_synth(m)
+    m = m.cuda().eval()
+    ref = load_synth(O.UformerAudio(drop_path_rate=0.0)).eval()
+    with torch.no_grad():
+        out = [o.float().cpu() for o in m(x.cuda(), msg.cuda())]
+        rout = ref(x, msg)
+    keys = ("stft_new", "noise", "wm_pred", "wm")
+    rec = {"batch": B, "eval_max_rel_dev": {k: rel(o, r) for k, o, r in zip(keys, out, rout)}}
+    bits_h, bits_r = out[3].round().clamp(0, 1), rout[3].round().clamp(0, 1)
+    rec["ber_hip_bf16"], rec["ber_cpu_fp32"] = float((bits_h - msg).abs().mean()), float((bits_r - msg).abs().mean())
+    rec["payload_bits_differing"] = float((bits_h != bits_r).float().mean())
+    lh, lr = O.train_losses(out, x, msg)[1], O.train_losses(rout, x, msg)[1]
+    rec["loss_terms_rel"] = [abs(float(a) - float(b)) / abs(float(b)) for a, b in zip(lh, lr)]
+    # gradients
+    m.train()
+    ref.train()
+    m.zero_grad(set_to_none=True)
+    o2 = m(x.cuda(), msg.cuda())
+    O.train_losses(o2, x.cuda(), msg.cuda())[0].backward()
+    O.train_losses(ref(x, msg), x, msg)[0].backward()
+    torch.cuda.synchronize()
+    g = {n: p.grad.detach().double().cpu() for n, p in m.named_parameters()}
+    rg = {n: p.grad.detach().double() for n, p in ref.named_parameters() if p.grad is not None}
+    worst = {}
+    for pre in ("encoder.", "decoder.", "decoder_wm.", "encoder_wm.", "input_proj.", "output_proj.", "stft_layer."):
+        a = torch.cat([g[n].flatten() for n in rg if n.startswith(pre)])
+        b = torch.cat([rg[n].flatten() for n in rg if n.startswith(pre)])
+        worst[pre] = {"norm_rel_err": ((a - b).norm() / b.norm()).item(), "cosine": (a @ b / (a.norm() * b.norm())).item()}
+    rec["grad_groups"] = worst
+    _record("r02_parity_bf16_b6.json", rec)
+    assert max(rec["eval_max_rel_dev"].values()) <= 5e-2, rec
+    assert rec["payload_bits_differing"] <= 0.01 and abs(rec["ber_hip_bf16"] - rec["ber_cpu_fp32"]) <= 0.01, rec
+    assert max(rec["loss_terms_rel"]) <= 2e-2, rec
+    for pre, e in worst.items():
+        assert e["norm_rel_err"] <= 8e-2 and e["cosine"] >= 0.997, (pre, e)
+
+
+def _full_attack_oracle(wm, net, B):
+    """The oracle's differentiable attack chain with the HIP kernels' own AWGN realisation for the CURRENT step."""
+    from oracle import attacks_torch as AT
+    cfg = wm.AttackConfig.full_stack()
+    z = wm.ops.awgn_noise(wm.attacks.rank_seed(cfg.seed), net._step_t, B, 8002).cpu()
+    return cfg, (lambda w: AT.attack_chain(w.double(), resample=True, snr_db=20.0, z=z.double(), lowpass=True, amp=0.8).float())
+
+
+def test_config3_full_attack_stack_forward_and_gradients(wm):
+    """BASELINE config 3: resample + AWGN (20 dB, replayed) + low-pass + x0.8 between iSTFT and STFT, extractor on the
+    attacked spectrogram; train mode (drop_path_rate = 0), fp32 parity mode: outputs, loss terms and gradients of
+    parameters on both sides of the attack against the oracle (autograd through its torch restatement of the chain)."""
+    B = 2
+    x, msg = synth_tile(B, "c3_x"), synth_bits("c3_msg", (B, 1, 32, 32))
+    m = wm.UformerAudio(modulator=True, drop_path_rate=0.0, compute_mode="fp32")
+    load_synth(m)
+    m = m.cuda().train()
+    m._ensure_runtime(torch.device("cuda"))
+    wm.ops.step_inc(m._step_t)                                   # forward() advances the counter once more: replay step 2
+    ref = load_synth(O.UformerAudio(drop_path_rate=0.0)).train()
+    m.attack, m.extract_from = wm.AttackConfig.full_stack(), "attacked"
+    m.zero_grad(set_to_none=True)
+    out = m(x.cuda(), msg.cuda())
+    cfg, attack = _full_attack_oracle(wm, m, B)                  # after the forward: the counter now holds the step it used
+    loss, terms = O.train_losses(out, x.cuda(), msg.cuda())
+    loss.backward()
+    rout = ref(x, msg, attack=attack, extract_from="attacked")
+    rloss, rterms = O.train_losses(rout, x, msg)
+    rloss.backward()
+    for o, r, k in zip(out, rout, ("stft_new", "noise", "wm_pred", "wm")):
+        assert rel(o, r.detach()) <= 2e-4, (k, rel(o, r.detach()))
+    np.testing.assert_allclose(torch.stack(terms).detach().cpu().numpy(), torch.stack(rterms).detach().numpy(), rtol=2e-4)
+    assert torch.equal(out[3].detach().round().clamp(0, 1).cpu(), rout[3].detach().round().clamp(0, 1))
+    names = ["decoder_wm.encoderlayer_0.blocks.0.attn.qkv.to_q.weight", "decoder_wm.conv2.weight", "stft_layer.0.weight",
+             "output_proj.proj.0.weight", "decoder.decoderlayer_3.blocks.1.mlp.linear2.0.weight",
+             "decoder.decoderlayer_0.blocks.3.attn.relative_position_bias_table", "decoder.upsample_0.deconv.0.weight",
+             "encoder.encoderlayer_2.blocks.5.mlp.dwconv.0.weight", "encoder.dowsample_1.conv.0.weight",
+             "encoder.conv.blocks.1.norm1.weight", "input_proj.proj.0.weight", "encoder_wm.conv1.weight"]
+    for n in names:
+        e = rel(m.get_parameter(n).grad, ref.get_parameter(n).grad)
+        assert e <= 3e-3, (n, e)
+
+
+def test_config5_ten_tile_clips_quadrant_payload(wm):
+    """BASELINE config 5 / row A14: 2 clips x 10 tiles (10 s at 16 kHz through the device data-prep STFT), a 64 x 64
+    grayscale payload per clip cut into quadrants over the tiles, full attack stack (AWGN replayed), train mode, fp32
+    parity mode, against the oracle: outputs, loss, selected gradients; decoded quadrants re-assembled bit-exactly."""
+    from synth import chirp_wave
+    clips, tpc = 2, 10
+    B = clips * tpc
+    waves = torch.stack([chirp_wave(10 * 16384 - 128, f"c5_{i}") for i in range(clips)]).cuda()
+    tiles, n_per = wm.dataprep.stft_tiles(waves)
+    x = tiles.view(clips, n_per, 2, 128, 128)[:, :tpc].reshape(B, 2, 128, 128).contiguous()
+    img = torch.rand(clips, 1, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    msg = wm.dataprep.payload_for_tiles(img, tpc).contiguous()
+    m = wm.UformerAudio(modulator=True, drop_path_rate=0.0, compute_mode="fp32")
+    load_synth(m)
+    m = m.cuda().train()
+    m.attack, m.extract_from = wm.AttackConfig.full_stack(), "attacked"
+    m.zero_grad(set_to_none=True)
+    out = m(x, msg)
+    cfg, attack = _full_attack_oracle(wm, m, B)
+    loss, terms = O.train_losses(out, x, msg)
+    loss.backward()
+    ref = load_synth(O.UformerAudio(drop_path_rate=0.0)).train()
+    rout = ref(x.cpu(), msg.cpu(), attack=attack, extract_from="attacked")
+    rloss, rterms = O.train_losses(rout, x.cpu(), msg.cpu())
+    rloss.backward()
+    for o, r, k in zip(out, rout, ("stft_new", "noise", "wm_pred", "wm")):
+        assert rel(o, r.detach()) <= 2e-4, (k, rel(o, r.detach()))
+    np.testing.assert_allclose(torch.stack(terms).detach().cpu().numpy(), torch.stack(rterms).detach().numpy(), rtol=2e-4)
+    for n in ("decoder_wm.conv.blocks.0.mlp.linear1.0.weight", "decoder.decoderlayer_2.blocks.0.attn.proj.weight",
+              "encoder.encoderlayer_0.blocks.0.norm2.bias", "encoder_wm.t_conv2.weight"):
+        e = rel(m.get_parameter(n).grad, ref.get_parameter(n).grad)
+        assert e <= 3e-3, (n, e)
+    # payload: per-tile quadrants -> 64 x 64 image, thresholded (grayscale payload: compare the rounded images)
+    got = wm.dataprep.payload_from_tiles(out[3].detach().round().clamp(0, 1), tpc).cpu()
+    want = wm.dataprep.payload_from_tiles(rout[3].detach().round().clamp(0, 1).cuda(), tpc).cpu()
+    assert torch.equal(got, want)
+
+
+def test_training_forward_advances_the_random_streams(wm):
+    """Reference-style loop (net(x, msg) in train mode, no TrainStep): consecutive forwards draw different DropPath masks
+    and AWGN realisations (the Philox step counter used to advance only inside TrainStep)."""
+    m = wm.UformerAudio(modulator=True, drop_path_rate=0.3)
+    load_synth(m)
+    m = m.cuda().train()
+    x, msg = synth_tile(4, "rs_x").cuda(), synth_bits("rs_m", (4, 1, 32, 32)).cuda()
+    with torch.no_grad():
+        a = m(x, msg)[1].clone()
+        b = m(x, msg)[1].clone()
+        assert not torch.equal(a, b)
+        m.eval()
+        c, d = m(x, msg)[1].clone(), m(x, msg)[1].clone()
+        assert torch.equal(c, d)                                 # eval: no stochastic depth, nothing advances
+        m.train()
+        m.arch.dp_rate = 0.0
+    m2 = wm.UformerAudio(modulator=True, drop_path_rate=0.0, attack=wm.AttackConfig(snr_db=10.0))
+    load_synth(m2)
+    m2 = m2.cuda().train()
+    with torch.no_grad():
+        e, f = m2(x, msg)[0].clone(), m2(x, msg)[0].clone()
+    assert not torch.equal(e, f)                                 # AWGN realisation differs per step
