@@ -118,12 +118,11 @@ def test_bf16_mode_bits_and_deviation(net, golden):
     finally:
         net.compute_mode = "fp32"
     dev = {k: rel(o, g[k]) for o, k in zip(out, ("stft_new", "noise", "wm_pred", "wm"))}
-    print("bf16 deviation vs fp32 reference:", dev)
-    assert max(dev.values()) < 0.1
     bits = out[3].round().clamp(0, 1).to(torch.uint8).cpu().numpy()
-    ber_vs_ref = np.mean(bits != g["bits"])
-    print("bf16 payload bit mismatches vs reference:", ber_vs_ref)
-    assert ber_vs_ref <= 0.01          # untrained synthetic net: sigmoid outputs within bf16 noise of 0.5 may flip
+    ber_vs_ref = float(np.mean(bits != g["bits"]))
+    _record("r02_parity_bf16_g3_b2.json", {"max_rel_dev_vs_reference_golden": dev, "payload_bits_differing": ber_vs_ref})
+    assert max(dev.values()) <= 3e-2, dev                          # measured 1.2e-2 (B = 6 twin below)
+    assert ber_vs_ref <= 0.005, ber_vs_ref  # untrained synthetic net: sigmoid outputs within bf16 noise of 0.5 may flip
 
 
 def test_attacked_forward_backward_runs_and_matches_oracle(net, wm):
@@ -287,9 +286,10 @@ def test_bf16_train_step_gradients_against_fp32_mode(wm):
         a, b = grads["bf16"][lo:hi], grads["fp32"][lo:hi]
         rec["buckets"][name] = {"norm_rel_err": ((a - b).norm() / b.norm()).item(), "cosine": (a @ b / (a.norm() * b.norm())).item()}
     _record("r02_parity_bf16_trainstep_b2.json", rec)
-    assert max(rec["loss_terms_rel"]) <= 2e-2, rec
+    # measured on MI355X (profiles/r02_parity_bf16_trainstep_b2.json): loss terms <= 2.4e-3, buckets <= 2.1e-2 / cosine >= 0.9997
+    assert max(rec["loss_terms_rel"]) <= 1e-2, rec
     for name, e in rec["buckets"].items():
-        assert e["norm_rel_err"] <= 6e-2 and e["cosine"] >= 0.998, (name, e)
+        assert e["norm_rel_err"] <= 4e-2 and e["cosine"] >= 0.999, (name, e)
 
 
 def test_bf16_whole_model_b6_against_cpu_oracle(wm):
@@ -329,11 +329,13 @@ def test_bf16_whole_model_b6_against_cpu_oracle(wm):
         worst[pre] = {"norm_rel_err": ((a - b).norm() / b.norm()).item(), "cosine": (a @ b / (a.norm() * b.norm())).item()}
     rec["grad_groups"] = worst
     _record("r02_parity_bf16_b6.json", rec)
-    assert max(rec["eval_max_rel_dev"].values()) <= 5e-2, rec
-    assert rec["payload_bits_differing"] <= 0.01 and abs(rec["ber_hip_bf16"] - rec["ber_cpu_fp32"]) <= 0.01, rec
-    assert max(rec["loss_terms_rel"]) <= 2e-2, rec
+    # measured on MI355X (profiles/r02_parity_bf16_b6.json): tensors <= 1.2e-2, 0.15 % of the (untrained, near-0.5) payload
+    # bits differ, loss terms <= 1.4e-2, gradient groups <= 1.9e-2 / cosine >= 0.9998
+    assert max(rec["eval_max_rel_dev"].values()) <= 3e-2, rec
+    assert rec["payload_bits_differing"] <= 0.005 and abs(rec["ber_hip_bf16"] - rec["ber_cpu_fp32"]) <= 0.005, rec
+    assert max(rec["loss_terms_rel"]) <= 3e-2, rec
     for pre, e in worst.items():
-        assert e["norm_rel_err"] <= 8e-2 and e["cosine"] >= 0.997, (pre, e)
+        assert e["norm_rel_err"] <= 4e-2 and e["cosine"] >= 0.999, (pre, e)
 
 
 def _full_attack_oracle(wm, net, B):
@@ -370,7 +372,7 @@ def test_config3_full_attack_stack_forward_and_gradients(wm):
     np.testing.assert_allclose(torch.stack(terms).detach().cpu().numpy(), torch.stack(rterms).detach().numpy(), rtol=2e-4)
     assert torch.equal(out[3].detach().round().clamp(0, 1).cpu(), rout[3].detach().round().clamp(0, 1))
     names = ["decoder_wm.encoderlayer_0.blocks.0.attn.qkv.to_q.weight", "decoder_wm.conv2.weight", "stft_layer.0.weight",
-             "output_proj.proj.0.weight", "decoder.decoderlayer_3.blocks.1.mlp.linear2.0.weight",
+             "output_proj.proj.0.weight", "decoder.decoderlayer_3.blocks.0.mlp.linear2.0.weight",
              "decoder.decoderlayer_0.blocks.3.attn.relative_position_bias_table", "decoder.upsample_0.deconv.0.weight",
              "encoder.encoderlayer_2.blocks.5.mlp.dwconv.0.weight", "encoder.dowsample_1.conv.0.weight",
              "encoder.conv.blocks.1.norm1.weight", "input_proj.proj.0.weight", "encoder_wm.conv1.weight"]
