@@ -83,10 +83,12 @@ _SIGS = {
     "wm_stft255_tiles": [c_f, c_i64, c_i32, c_f, c_fl, c_f],
     "wm_istft255_stitch": [c_f, c_i32, c_i32, c_i32, c_f, c_i64, c_fl, c_f],
     "wm_wave_attack": [C.POINTER(WmWaveAttack), c_f, c_f, c_i64, c_i32, c_f, c_f],
-    "wm_istft255_fwd": [c_f, c_f, c_i32, c_f],
-    "wm_stft255_fwd": [c_f, c_f, c_i32, c_f],
-    "wm_istft255_bwd": [c_f, c_f, c_i32, c_f],
-    "wm_stft255_bwd": [c_f, c_f, c_i32, c_f],
+    "wm_stft255_table_bytes": [],
+    "wm_stft255_tables": [c_f, c_f],
+    "wm_istft255_fwd": [c_f, c_f, c_f, c_i32, c_f],
+    "wm_stft255_fwd": [c_f, c_f, c_f, c_i32, c_f],
+    "wm_istft255_bwd": [c_f, c_f, c_f, c_i32, c_f],
+    "wm_stft255_bwd": [c_f, c_f, c_f, c_i32, c_f],
     "wm_attack_fwd": [C.POINTER(WmAttack), c_f, c_f, c_f, c_i32, c_i32, c_f],
     "wm_attack_bwd": [C.POINTER(WmAttack), c_f, c_f, c_f, c_f, c_i32, c_i32, c_f],
     "wm_awgn_noise": [c_u64, c_f, c_f, c_i32, c_i32, c_f],
@@ -121,7 +123,7 @@ def _load():
     for name, args in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError here = ABI drift between header and library
         fn.argtypes = args
-        fn.restype = C.c_int64 if name.endswith("_floats") else C.c_int
+        fn.restype = C.c_int64 if name.endswith(("_floats", "_bytes")) else C.c_int
     return lib
 
 

@@ -572,7 +572,7 @@ int dispatch(const WmGemm& g, int ksplit, hipStream_t st) {
 
 int wm_gemm_fast_bf16(const WmGemm& g, hipStream_t st);   // gemm_fast.hip: branch-free bf16 kernels, -1 = not applicable
 
-extern "C" int wm_abi_version(void) { return 2; }
+extern "C" int wm_abi_version(void) { return 3; }
 extern "C" int64_t wm_gemm_scratch_floats(void) { return 384LL * 128 * 128 + 1024 * 1024; }
 
 extern "C" int wm_gemm(const WmGemm* gp, void* stream) {

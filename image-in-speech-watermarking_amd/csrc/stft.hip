@@ -1,21 +1,15 @@
-// In-graph STFT round trip of the watermark model (reference model.py:2458 torch.istft and :2463
-// torch.stft, both n_fft = 255 with every other argument defaulted): 128 one-sided bins, hop 63,
-// rectangular window of 255, center=True with reflect padding, no normalisation.
-//   spec  : [B, 2, 128 bins, 128 frames]  (re | im planes, as the model holds it)
-//   wave  : [B, 8002]
-// 255 = 3*5*17 is not a power of two, so the transform is evaluated as a direct real DFT against a
-// 255-entry cos/sin table held in LDS; the twiddle index k*n mod 255 is advanced incrementally.
-// Frames (iSTFT) / samples (STFT) of a chunk are staged in LDS once and reused by every output.
-// The backward passes are the same two kernels in "adjoint" mode:
-//   d(istft)/dspec  = weighted zero-padded STFT of dwave / envelope
-//   d(stft)/dwave   = unweighted overlap-add synthesis of dspec folded through the reflect padding.
+// Data-side and evaluation-side transforms on whole utterances (the in-graph n_fft = 255 round trip of the train step
+// lives in stft_mfma.hip): the data-prep STFT (256 / 128), the whole-utterance STFT (255 / 63) cut into tiles, the
+// stitching iSTFT, and the state-free evaluation attacks.  torch conventions throughout: rectangular window,
+// center=True with reflect padding, no normalisation; tiles are [2, 128 bins, 128 frames] (re | im planes).
+// 255 = 3*5*17 is not a power of two: these (outside the train step) evaluate a direct real DFT against a 255-entry
+// cos/sin table held in LDS, the twiddle index k*n mod 255 advanced incrementally.
 #include "common.h"
 #include "../../include/wm_kernels.h"
 
 namespace {
 
-constexpr int NFFT = 255, HOP = 63, NBIN = 128, NFRAME = 128, WLEN = 8002, PADL = 127;
-constexpr int OLA_LEN = NFFT + HOP * (NFRAME - 1);     // 8256
+constexpr int NFFT = 255, HOP = 63, NBIN = 128, NFRAME = 128, PADL = 127;
 constexpr int CHUNK = 512;                             // output samples per workgroup (synthesis)
 constexpr int MAXF = 16;                               // frames staged per synthesis chunk
 constexpr int TG = 16;                                 // frames per workgroup (analysis)
@@ -53,101 +47,6 @@ __device__ __forceinline__ float synth_at(int q, const float2* Xs, int t0, const
     total += ADJ ? (acc + a2) : (acc + 2.0f * a2);
   }
   return ADJ ? total : total / (float)(NFFT * cnt);
-}
-
-// ADJ = false : wave = istft(spec)              (out has WLEN samples per row)
-// ADJ = true  : dwave = stft^T(dspec)           (same shape; reflect padding folded back)
-template <bool ADJ>
-__global__ __launch_bounds__(256) void synth_kernel(const float* __restrict__ spec, float* __restrict__ wave) {
-  __shared__ float2 Xs[NBIN * MAXF];
-  __shared__ float2 tw[NFFT + 1];
-  const int tid = threadIdx.x, b = blockIdx.y, i0 = blockIdx.x * CHUNK;
-  const int i1 = min(WLEN, i0 + CHUNK);
-  int qlo = i0 + PADL, qhi = i1 - 1 + PADL;
-  if (ADJ) {
-    if (i0 == 0) qlo = 0;
-    if (i1 == WLEN) qhi = OLA_LEN - 1;
-  }
-  int t0;
-  frames_covering(qlo, t0);
-  int t1 = qhi / HOP;
-  if (t1 > NFRAME - 1) t1 = NFRAME - 1;
-  const int nf = t1 - t0 + 1;                            // <= MAXF by construction
-  for (int m = tid; m < NFFT; m += 256) {
-    double sn, cs;
-    sincospi(2.0 * (double)m / (double)NFFT, &sn, &cs);
-    tw[m] = make_float2((float)cs, (float)sn);
-  }
-  const float* src = spec + (int64_t)b * 2 * NBIN * NFRAME;
-  for (int idx = tid; idx < NBIN * MAXF; idx += 256) {
-    const int k = idx / MAXF, tt = idx % MAXF;
-    Xs[idx] = tt < nf ? make_float2(src[k * NFRAME + t0 + tt], src[(NBIN + k) * NFRAME + t0 + tt]) : make_float2(0.f, 0.f);
-  }
-  __syncthreads();
-  for (int i = i0 + tid; i < i1; i += 256) {
-    float v = synth_at<ADJ>(i + PADL, Xs, t0, tw);
-    if (ADJ) {
-      if (i >= 1 && i <= PADL) v += synth_at<true>(PADL - i, Xs, t0, tw);
-      if (i >= WLEN - 1 - PADL && i <= WLEN - 2) v += synth_at<true>(2 * (WLEN - 1) - i + PADL, Xs, t0, tw);
-    }
-    wave[(int64_t)b * WLEN + i] = v;
-  }
-}
-
-// ADJ = false : spec = stft(wave)                (reflect padding)
-// ADJ = true  : dspec = istft^T(dwave)           (zero padding, 1/envelope on the samples, w_k/255 on bins)
-template <bool ADJ>
-__global__ __launch_bounds__(256) void analysis_kernel(const float* __restrict__ wave, float* __restrict__ spec) {
-  __shared__ float fs[SPAN];
-  __shared__ float2 tw[NFFT + 1];
-  const int tid = threadIdx.x, b = blockIdx.y, tg0 = blockIdx.x * TG;
-  for (int m = tid; m < NFFT; m += 256) {
-    double sn, cs;
-    sincospi(2.0 * (double)m / (double)NFFT, &sn, &cs);
-    tw[m] = make_float2((float)cs, (float)sn);
-  }
-  const float* src = wave + (int64_t)b * WLEN;
-  for (int s = tid; s < SPAN; s += 256) {
-    const int q = HOP * tg0 + s;                          // OLA / padded coordinate
-    int i = q - PADL;
-    float v;
-    if (ADJ) {
-      int tlo;
-      v = (i >= 0 && i < WLEN) ? src[i] / (float)frames_covering(q, tlo) : 0.f;
-    } else {
-      if (i < 0) i = -i;
-      if (i >= WLEN) i = 2 * (WLEN - 1) - i;
-      v = src[i];
-    }
-    fs[s] = v;
-  }
-  __syncthreads();
-  const int k = tid & (NBIN - 1), half = tid >> 7;        // 8 frames per thread
-  float re[TG / 2], im[TG / 2];
-#pragma unroll
-  for (int f = 0; f < TG / 2; ++f) { re[f] = 0.f; im[f] = 0.f; }
-  const float* base = fs + HOP * (half * (TG / 2));
-  int idx = 0;
-  for (int n = 0; n < NFFT; ++n) {
-    const float2 w = tw[idx];
-    const float c = w.x, s = w.y;
-#pragma unroll
-    for (int f = 0; f < TG / 2; ++f) {
-      const float x = base[HOP * f + n];
-      re[f] += x * c;
-      im[f] -= x * s;
-    }
-    idx += k;
-    if (idx >= NFFT) idx -= NFFT;
-  }
-  float wk = 1.f;
-  if (ADJ) wk = (k == 0 ? 1.0f : 2.0f) / (float)NFFT;
-  float* dst = spec + (int64_t)b * 2 * NBIN * NFRAME + k * NFRAME + tg0 + half * (TG / 2);
-#pragma unroll
-  for (int f = 0; f < TG / 2; ++f) {
-    dst[f] = re[f] * wk;
-    dst[NBIN * NFRAME + f] = (ADJ && k == 0) ? 0.f : im[f] * wk;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -369,34 +268,6 @@ extern "C" int wm_stft256_tiles(const float* wave, int64_t L, int32_t U, float* 
   return WM_OK;
 }
 
-extern "C" int wm_istft255_fwd(const float* spec, float* wave, int32_t B, void* stream) {
-  if (!spec || !wave || B <= 0) return WM_EINVAL;
-  hipLaunchKernelGGL(synth_kernel<false>, dim3((WLEN + CHUNK - 1) / CHUNK, B), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), spec, wave);
-  WM_CHECK_LAUNCH();
-  return WM_OK;
-}
-extern "C" int wm_stft255_bwd(const float* dspec, float* dwave, int32_t B, void* stream) {
-  if (!dspec || !dwave || B <= 0) return WM_EINVAL;
-  hipLaunchKernelGGL(synth_kernel<true>, dim3((WLEN + CHUNK - 1) / CHUNK, B), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), dspec, dwave);
-  WM_CHECK_LAUNCH();
-  return WM_OK;
-}
-extern "C" int wm_stft255_fwd(const float* wave, float* spec, int32_t B, void* stream) {
-  if (!wave || !spec || B <= 0) return WM_EINVAL;
-  hipLaunchKernelGGL(analysis_kernel<false>, dim3(NFRAME / TG, B), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     wave, spec);
-  WM_CHECK_LAUNCH();
-  return WM_OK;
-}
-extern "C" int wm_istft255_bwd(const float* dwave, float* dspec, int32_t B, void* stream) {
-  if (!dwave || !dspec || B <= 0) return WM_EINVAL;
-  hipLaunchKernelGGL(analysis_kernel<true>, dim3(NFRAME / TG, B), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     dwave, dspec);
-  WM_CHECK_LAUNCH();
-  return WM_OK;
-}
 
 extern "C" int32_t wm_stft255_tiles_per_utterance(int64_t L) {
   const int64_t frames = 1 + (L - 1) / HOP;                   // centre padding adds 2 * 127 = n_fft - 1 samples

@@ -177,10 +177,15 @@ int wm_wave_attack(const WmWaveAttack* a, const float* wave, float* out, int64_t
 
 /* ---- in-graph STFT round trip — torch.istft / torch.stft with n_fft=255, hop 63, rectangular
  * window, center/reflect (model.py:2458,2463).  spec: [B,2,128,128] (re|im planes), wave: [B,8002] */
-int wm_istft255_fwd(const float* spec, float* wave, int32_t B, void* stream);
-int wm_stft255_fwd(const float* wave, float* spec, int32_t B, void* stream);
-int wm_istft255_bwd(const float* dwave, float* dspec, int32_t B, void* stream);
-int wm_stft255_bwd(const float* dspec, float* dwave, int32_t B, void* stream);
+/* `tables`: wm_stft255_table_bytes() bytes of caller-owned device memory (16-byte aligned) filled ONCE by
+ * wm_stft255_tables(): the folded cos / sin DFT matrices in bf16 hi + lo halves, in MFMA operand order.  The transforms
+ * run as split-precision bf16 MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate: ~2e-6 of full scale).           */
+int64_t wm_stft255_table_bytes(void);
+int wm_stft255_tables(void* tables, void* stream);
+int wm_istft255_fwd(const float* spec, float* wave, const void* tables, int32_t B, void* stream);
+int wm_stft255_fwd(const float* wave, float* spec, const void* tables, int32_t B, void* stream);
+int wm_istft255_bwd(const float* dwave, float* dspec, const void* tables, int32_t B, void* stream);
+int wm_stft255_bwd(const float* dspec, float* dwave, const void* tables, int32_t B, void* stream);
 
 /* ---- waveform attacks (audio_attack.py:21-30,55-58,71-83,99-125; torch awgn model.py:15-41).
  * One workgroup per waveform keeps the row in LDS through the whole chain.

@@ -389,6 +389,41 @@ def test_stft_istft_fwd_bwd(wm, golden):
     assert_close(sp, torch.from_numpy(g2["spec"]), 1e-4, "stft vs golden")
 
 
+def test_stft_round_trip_is_deterministic_under_load(wm):
+    """The four n_fft = 255 transforms at a bench-like batch (several workgroups resident per CU), launched repeatedly:
+    bit-identical results every time and within 1e-4 of torch.stft / torch.istft (float64) for every tile.  A build of
+    these kernels with packed-fp32 folds failed exactly this on MI355X (wrong sums in one half-wave under load)."""
+    ops = wm.ops
+    B = 96
+    g = torch.Generator().manual_seed(3)
+    w = (0.2 * torch.randn(B, 8002, generator=g)).cuda()
+    sp = torch.randn(B, 2, 128, 128, generator=g).cuda()
+    win = torch.ones(255, dtype=torch.float64)
+    st = torch.view_as_real(torch.stft(w.double().cpu(), n_fft=255, window=win, return_complex=True)).permute(0, 3, 1, 2)
+    wv = torch.istft(torch.complex(sp[:, 0].double().cpu(), sp[:, 1].double().cpu()), n_fft=255, window=win)
+    outs = None
+    for rep in range(12):
+        s, x = torch.empty(B, 2, 128, 128, device="cuda"), torch.empty(B, 8002, device="cuda")
+        ds, dx = torch.empty(B, 2, 128, 128, device="cuda"), torch.empty(B, 8002, device="cuda")
+        ops.stft_fwd(w, s, B)
+        ops.istft_fwd(sp, x, B)
+        ops.istft_bwd(w, ds, B)
+        ops.stft_bwd(sp, dx, B)
+        cur = (s, x, ds, dx)
+        if outs is None:
+            outs = cur
+            assert_close(s, st, 1e-4, "stft at B = 96")
+            assert_close(x, wv, 1e-4, "istft at B = 96")
+            # adjoint identities tie the backward kernels to the forward ones
+            lhs, rhs = (x.double() * w.double()).sum().item(), (sp.double() * ds.double()).sum().item()
+            assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0), (lhs, rhs)
+            lhs, rhs = (s.double() * sp.double()).sum().item(), (w.double() * dx.double()).sum().item()
+            assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0), (lhs, rhs)
+        else:
+            for a, b_, name in zip(cur, outs, ("stft_fwd", "istft_fwd", "istft_bwd", "stft_bwd")):
+                assert torch.equal(a, b_), f"{name}: launch {rep} differs from launch 0"
+
+
 # ---------------------------------------------------------------------------------- attacks
 def test_attacks_fwd_and_adjoint(wm):
     att = wm.attacks
