@@ -41,7 +41,7 @@ class WmConv(C.Structure):
 class WmAttack(C.Structure):
     _fields_ = [("flags", c_i32), ("snr_db", c_fl), ("amp", c_fl), ("lp_h", c_f), ("lp_n", c_i32),
                 ("rs_h", c_f), ("rs_n", c_i32), ("seed", c_u64), ("step", c_f),
-                ("echo_delay", c_i32), ("echo_gain", c_fl), ("jitter_count", c_i32), ("reserved", c_i32)]
+                ("echo_delay", c_i32), ("echo_gain", c_fl), ("jitter_count", c_i32), ("reserved", c_i32), ("lp_mfma", c_f)]
 
 
 class WmWaveAttack(C.Structure):
@@ -89,6 +89,8 @@ _SIGS = {
     "wm_stft255_fwd": [c_f, c_f, c_f, c_i32, c_f],
     "wm_istft255_bwd": [c_f, c_f, c_f, c_i32, c_f],
     "wm_stft255_bwd": [c_f, c_f, c_f, c_i32, c_f],
+    "wm_attack_fir_table_bytes": [],
+    "wm_attack_fir_tables": [c_f, c_i32, c_f, c_f],
     "wm_attack_fwd": [C.POINTER(WmAttack), c_f, c_f, c_f, c_i32, c_i32, c_f],
     "wm_attack_bwd": [C.POINTER(WmAttack), c_f, c_f, c_f, c_f, c_i32, c_i32, c_f],
     "wm_awgn_noise": [c_u64, c_f, c_f, c_i32, c_i32, c_f],

@@ -58,6 +58,7 @@ class AttackConfig:
     echo: Optional[tuple] = None          # (delay in samples, gain): audio_attack.py:33-52 uses (8000, 0.2)
     jitter: Optional[int] = None          # number of zeroed samples per row (jittering_2, :176-193)
     requantize: bool = False              # 8-bit PCM round trip (:85-96), straight-through gradient
+    mfma_fir: bool = True                 # low-pass passes on the matrix cores (False: the scalar fp32 loops)
 
     @property
     def flags(self):
@@ -116,17 +117,27 @@ def rank_seed(seed):
 
 
 def _device_tables(device):
+    """(low-pass taps | tails, resampling taps, MFMA operand image of the low-pass taps) on `device`, built once (outside
+    any graph capture: the first, eager, call makes them)."""
     key = str(device)
     if key not in _tables:
-        _tables[key] = (torch.from_numpy(lowpass_fir_tables()).to(device), torch.from_numpy(resample_fir_table()).to(device))
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("attack tables: first use inside a graph capture; run one eager step first")
+        lp, rs = torch.from_numpy(lowpass_fir_tables()).to(device), torch.from_numpy(resample_fir_table()).to(device)
+        fir = torch.empty(int(ops.lib.wm_attack_fir_table_bytes()) // 2, device=device, dtype=torch.bfloat16)
+        ops.check(ops.lib.wm_attack_fir_tables(ptr(lp), LP_TAPS, ptr(fir), torch.cuda.current_stream().cuda_stream),
+                  "wm_attack_fir_tables")
+        torch.cuda.current_stream().synchronize()
+        _tables[key] = (lp, rs, fir)
     return _tables[key]
 
 
 def _desc(cfg, device, step):
-    lp, rs = _device_tables(device)
+    lp, rs, fir = _device_tables(device)
     delay, gain = cfg.echo if cfg.echo is not None else (0, 0.0)
     return WmAttack(cfg.flags, float(cfg.snr_db or 0.0), float(cfg.amp if cfg.amp is not None else 1.0), ptr(lp),
-                    LP_TAPS, ptr(rs), 41, rank_seed(cfg.seed), ptr(step), int(delay), float(gain), int(cfg.jitter or 0), 0)
+                    LP_TAPS, ptr(rs), 41, rank_seed(cfg.seed), ptr(step), int(delay), float(gain), int(cfg.jitter or 0), 0,
+                    ptr(fir) if cfg.mfma_fir else None)
 
 
 def attack_forward(cfg, wave, step, out=None, sigma=None):

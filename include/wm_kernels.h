@@ -199,7 +199,12 @@ typedef struct WmAttack {
   const float* rs_h; int32_t rs_n;          /* polyphase resampling prototype filter              */
   uint64_t seed; const int64_t* step;       /* Philox stream = (seed, *step, row)                 */
   int32_t echo_delay; float echo_gain; int32_t jitter_count; int32_t reserved;
-} WmAttack;
+  const void* lp_mfma;                      /* optional: wm_attack_fir_tables() image of lp_h (lp_n == 128): the two FIR   */
+} WmAttack;                                 /* passes then run as split-precision bf16 MFMA products; NULL = scalar loops   */
+/* Banded-Toeplitz operand tables of the 128-tap low-pass response for the MFMA form of the FIR passes:
+ * wm_attack_fir_table_bytes() bytes of caller-owned device memory (16-byte aligned), filled once per filter.             */
+int64_t wm_attack_fir_table_bytes(void);
+int wm_attack_fir_tables(const float* lp_h, int32_t lp_n, void* tables, void* stream);
 int wm_attack_fwd(const WmAttack* a, const float* wave, float* out, float* sigma_out, int32_t B, int32_t L,
                   void* stream);
 int wm_attack_bwd(const WmAttack* a, const float* wave, const float* dout, const float* sigma, float* dwave,

@@ -475,6 +475,37 @@ def test_attacks_fwd_and_adjoint(wm):
     assert abs(fd - (dgr * v).sum()) <= 2e-3 * abs(fd) + 1e-6
 
 
+def test_attack_lowpass_on_matrix_cores_equals_scalar_loops(wm):
+    """The MFMA form of the two 128-tap FIR passes (Toeplitz operand tables, split-precision bf16) against the fp32 scalar
+    loops of the same kernel, forward and backward, full stack incl. AWGN, at a batch that fills every CU."""
+    att = wm.attacks
+    B, L = 300, 8002
+    g = torch.Generator().manual_seed(11)
+    x = (0.1 * torch.randn(B, L, generator=g)).cuda()
+    gy = torch.randn(B, L, generator=g).cuda()
+    step = torch.full((1,), 3, dtype=torch.int64, device="cuda")
+    res = {}
+    for mfma in (True, False):
+        cfg = att.AttackConfig(resample=True, snr_db=20.0, lowpass=True, amp=0.8, seed=7, mfma_fir=mfma)
+        y, sg = att.attack_forward(cfg, x, step)
+        dx = att.attack_backward(cfg, x, gy, sg, step)
+        res[mfma] = (y, dx)
+    assert_close(res[True][0], res[False][0], 2e-5, "attack forward: MFMA FIR vs scalar FIR")
+    assert_close(res[True][1], res[False][1], 2e-5, "attack backward: MFMA FIR vs scalar FIR")
+    y2, _ = att.attack_forward(att.AttackConfig.full_stack(), x, step)
+    assert torch.equal(y2, res[True][0])                                     # deterministic
+    # odd and short rows through the edge paths of the half-band resampler, against the oracle
+    for L2 in (801, 64, 8001):
+        xs = 0.1 * torch.randn(2, L2, generator=g)
+        c = att.AttackConfig(resample=True, lowpass=True, amp=0.8)
+        o, _ = att.attack_forward(c, xs.cuda(), step)
+        assert_close(o, torch.from_numpy(OA.attack_chain(xs.numpy(), resample=True, lowpass=True, amp=0.8)), 1e-4, f"L = {L2}")
+        gg = torch.randn(2, L2, generator=g)
+        atg = att.attack_backward(c, xs.cuda(), gg.cuda(), None, step)
+        lhs, rhs = (o.double().cpu() * gg.double()).sum(-1), (xs.double() * atg.double().cpu()).sum(-1)
+        assert_close(lhs, rhs, 1e-4, f"adjoint identity, L = {L2}")
+
+
 def test_attack_row_n3_stages_fwd_and_adjoint(wm):
     """In-loop echo / jittering_2 / requantisation behind the four BASELINE attacks."""
     att = wm.attacks
