@@ -98,6 +98,14 @@ _SIGS = {
     "wm_charbonnier_fwd_bwd": [c_f, c_f, c_i64, c_fl, c_f, c_f, c_f, c_fl, c_f],
     "wm_tvloss_fwd_bwd": [c_f, c_i32, c_i32, c_i32, c_i32, c_fl, c_f, c_f, c_fl, c_f],
     "wm_tv_pow_fwd_bwd": [c_f, c_i32, c_i32, c_i32, c_i32, c_fl, c_fl, c_f, c_f, c_fl, c_f],
+    "wm_crop2d": [c_f, c_f] + [c_i32] * 8 + [c_f],
+    "wm_blend2d": [c_f, c_f, c_f, c_f, c_f] + [c_i32] * 8 + [c_f],
+    "wm_bernoulli_mask": [c_f, c_i32, c_fl, c_u64, c_u64, c_f],
+    "wm_resize_nearest": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_fl, c_fl, c_i32, c_f],
+    "wm_quantization_state_bytes": [],
+    "wm_quantization_fwd": [c_f, c_f, c_f, c_i64, c_f, c_f],
+    "wm_quantization_bwd": [c_f, c_f, c_f, c_f, c_i64, c_f, c_f],
+    "wm_jpeg_mask": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_adamw": [c_f, c_f, c_f, c_f, c_i64, c_f, c_fl, c_fl, c_fl, c_fl, c_f, c_f, c_f],
     "wm_step_inc": [c_f, c_f],
     "wm_droppath_scales": [c_f, c_f, c_i32, c_i32, c_u64, c_f, c_f],

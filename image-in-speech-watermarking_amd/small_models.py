@@ -271,32 +271,6 @@ class HiddenDecoder(nn.Module):
         return run_layers(self.layers, x, self.training)
 
 
-class Identity(nn.Module):
-    """hidden/noise_layers/identity.py:4-12: returns its [noised, cover] list unchanged."""
-
-    def forward(self, noised_and_cover):
-        return noised_and_cover
-
-
-class Noiser(nn.Module):
-    """hidden/noise_layers/noiser.py:8-31: holds a list of noise layers (Identity always first) and applies ONE, drawn
-    with numpy's global RNG, to the ``[noised, cover]`` list.  Only ``Identity`` is on the audio path (the other HiDDeN
-    layers are image-domain distortions)."""
-
-    def __init__(self, noise_layers=(), device=None):
-        super().__init__()
-        self.noise_layers = [Identity()]
-        for layer in noise_layers:
-            if isinstance(layer, str):
-                if layer not in ("Identity", "identity"):
-                    raise ValueError(f"noise layer {layer!r} is an image-domain HiDDeN distortion, not on the audio path")
-                layer = Identity()
-            self.noise_layers.append(layer)
-
-    def forward(self, encoded_and_cover):
-        return np.random.choice(self.noise_layers, 1)[0](encoded_and_cover)
-
-
 def decoded_ber(decoded, message):
     """hidden/test_model.py:60-64: mean |round(clip(decoded, 0, 1)) - message| (host numpy, as the reference does)."""
     rounded = decoded.detach().cpu().numpy().round().clip(0, 1)

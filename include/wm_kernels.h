@@ -263,6 +263,32 @@ int wm_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint
 int wm_mse_fwd_bwd(const float* a, const float* b, int64_t n, float* loss, float* da, float* db, float gscale,
                    void* stream);
 
+/* ---- HiDDeN image-domain distortions on [B, C, H, W] fp32 tiles (hidden/noise_layers/).  The random
+ * rectangles / ratios / masks are drawn by the caller as the reference draws them (numpy) and passed in.  backward != 0
+ * selects the adjoint / gradient form of the same entry point.
+ *   wm_crop2d          crop.py:48-74: dst[p, i, j] = src[p, h0 + i, w0 + j] (oh x ow); backward: src = dy [p, oh, ow] -> dst = dx
+ *   wm_blend2d         cropout.py:6-27 (rectangle [h0, h1) x [w0, w1)) / dropout.py:5-29 (mask[H * W] != 0): out0 = sel ? a : b;
+ *                      backward: a = dy, out0 = d/da (or NULL), out1 = d/db (or NULL)
+ *   wm_bernoulli_mask  device-side keep mask for Dropout (Philox; the numpy stream of dropout.py:22 is the compatible default)
+ *   wm_resize_nearest  resize.py:6-26 F.interpolate(mode='nearest'): src index = min(floor(dst * scale), in - 1), scale =
+ *                      float(1 / ratio); backward ACCUMULATES dy into a zeroed dx
+ *   wm_quantization_*  quantization.py:17-45: rescale to [0, 255], Fourier soft rounding, rescale to the input's range; f: [n]
+ *                      scratch kept for the backward, state: wm_quantization_state_bytes() bytes kept for the backward
+ *   wm_jpeg_mask       jpeg_compression.py:65-160 on [B, 3, H, W]: RGB -> YUV, 8x8 DCT, zig-zag keep masks, inverse, YUV -> RGB;
+ *                      adjoint != 0: the adjoint map (gradient with respect to the input)                                  */
+int wm_crop2d(const float* src, float* dst, int32_t planes, int32_t H, int32_t W, int32_t h0, int32_t w0, int32_t oh, int32_t ow,
+              int32_t backward, void* stream);
+int wm_blend2d(const float* a, const float* b, const float* mask, float* out0, float* out1, int32_t planes, int32_t H, int32_t W,
+               int32_t h0, int32_t h1, int32_t w0, int32_t w1, int32_t backward, void* stream);
+int wm_bernoulli_mask(float* mask, int32_t n, float keep, uint64_t seed, uint64_t offset, void* stream);
+int wm_resize_nearest(const float* src, float* dst, int32_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW, float scale_h,
+                      float scale_w, int32_t backward, void* stream);
+int64_t wm_quantization_state_bytes(void);
+int wm_quantization_fwd(const float* x, float* f, float* out, int64_t n, void* state, void* stream);
+int wm_quantization_bwd(const float* g, const float* x, const float* f, float* dx, int64_t n, void* state, void* stream);
+int wm_jpeg_mask(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t keep_y, int32_t keep_u, int32_t keep_v,
+                 int32_t adjoint, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,3 +147,40 @@ def test_eval_path_restatement_round_trip_and_tiling():
     short = E.stitch_istft(clips[:1], 10, 2000)                    # length beyond the overlap-add: zero padded
     assert torch.count_nonzero(short[255 + 63 * 9 - 127:]) == 0
     assert abs(E.signaltonoise(np.array([1.0, 2.0, 3.0])) - 20 * np.log10(2 / np.sqrt(2 / 3))) < 1e-12
+
+
+def test_noise_layer_oracle_matches_reference_golden(golden):
+    """oracle/noise_layers.py against outputs of the reference's own hidden/noise_layers modules (G7); the random draws are
+    replayed by seeding numpy as the generator script did and making the reference's numpy calls in its order."""
+    import numpy as np
+    from oracle import noise_layers as N
+    from synth import synth_array
+    g = golden("g7_noise_layers")
+
+    def rand_rect(H, W, hr, wr):
+        rh = int(np.rint((np.random.rand() * (hr[1] - hr[0]) + hr[0]) * H))
+        rw = int(np.rint((np.random.rand() * (wr[0] - wr[0]) + wr[0]) * W))          # crop.py:32 draws from (w0, w0)
+        h0 = 0 if rh == H else np.random.randint(0, H - rh)
+        w0 = 0 if rw == W else np.random.randint(0, W - rw)
+        return h0, h0 + rh, w0, w0 + rw
+    x = lambda name, C, H, W: (synth_array(f"g7_{name}_n", (2, C, H, W)), synth_array(f"g7_{name}_c", (2, C, H, W)))
+    n, c = x("crop", 2, 40, 56)
+    np.random.seed(11)
+    np.testing.assert_allclose(N.crop(n, *rand_rect(40, 56, (0.4, 0.7), (0.5, 0.8))).numpy(), g["crop_y"], rtol=1e-6)
+    n, c = x("cropout", 2, 40, 56)
+    np.random.seed(12)
+    np.testing.assert_allclose(N.cropout(n, c, *rand_rect(40, 56, (0.3, 0.6), (0.4, 0.6))).numpy(), g["cropout_y"], rtol=1e-6)
+    n, c = x("dropout", 2, 40, 56)
+    np.random.seed(13)
+    p = np.random.uniform(0.25, 0.45)
+    mask = torch.tensor(np.random.choice([0.0, 1.0], (40, 56), p=[1 - p, p]), dtype=torch.float)
+    np.testing.assert_allclose(N.dropout(n, c, mask).numpy(), g["dropout_y"], rtol=1e-6)
+    for name, C, H, W, seed, rr in (("resize_down", 2, 40, 56, 14, (0.45, 0.75)), ("resize_up", 1, 24, 20, 15, (1.3, 1.7))):
+        n, c = x(name, C, H, W)
+        np.random.seed(seed)
+        np.testing.assert_allclose(N.resize(n, np.random.rand() * (rr[1] - rr[0]) + rr[0]).numpy(), g[name + "_y"], rtol=1e-6)
+    n, c = x("quant", 2, 40, 56)
+    np.testing.assert_allclose(N.quantization(n).numpy(), g["quant_y"], rtol=1e-4, atol=1e-4)
+    for name, H, W in (("jpeg", 40, 52), ("jpeg128", 128, 128)):
+        n, c = x(name, 3, H, W)
+        np.testing.assert_allclose(N.jpeg(n).numpy(), g[name + "_y"], rtol=1e-4, atol=2e-5)
