@@ -85,6 +85,8 @@ _SIGS = {
     "wm_wave_attack": [C.POINTER(WmWaveAttack), c_f, c_f, c_i64, c_i32, c_f, c_f],
     "wm_stft255_table_bytes": [],
     "wm_stft255_tables": [c_f, c_f],
+    "wm_wave_lowpass": [c_f, c_f, c_f, c_i64, c_i32, c_f, c_i32, c_f],
+    "wm_wave_resample": [c_f, c_f, c_f, c_i64, c_i32, c_f, c_i32, c_f],
     "wm_istft255_fwd": [c_f, c_f, c_f, c_i32, c_f],
     "wm_stft255_fwd": [c_f, c_f, c_f, c_i32, c_f],
     "wm_istft255_bwd": [c_f, c_f, c_f, c_i32, c_f],

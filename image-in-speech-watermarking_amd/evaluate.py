@@ -50,6 +50,33 @@ def _mse(a, b, out=None):
     return loss
 
 
+def wave_lowpass(wave):
+    """Butterworth-8 zero-phase low-pass at half band (audio_attack.py:21-30) of [U, L] waveforms of any length."""
+    from .attacks import _device_tables, LP_TAPS
+    from ._lib import check, lib, ptr
+    wave = wave.contiguous().float()
+    U, L = wave.shape
+    lp, _, _ = _device_tables(wave.device)
+    out, tmp = torch.empty_like(wave), torch.empty(U, L + 54, device=wave.device)
+    check(lib.wm_wave_lowpass(ptr(wave), ptr(out), ptr(tmp), L, U, ptr(lp), LP_TAPS, torch.cuda.current_stream().cuda_stream),
+          "wm_wave_lowpass")
+    return out
+
+
+def wave_resample(wave):
+    """16 kHz -> 8 kHz -> 16 kHz (audio_attack.py:71-83) of [U, L] waveforms: polyphase half-band Kaiser filter, scipy
+    resample_poly conventions, output length L (the reference's librosa kernel is parity-unpinned)."""
+    from .attacks import _device_tables
+    from ._lib import check, lib, ptr
+    wave = wave.contiguous().float()
+    U, L = wave.shape
+    _, rs, _ = _device_tables(wave.device)
+    out, tmp = torch.empty_like(wave), torch.empty(U, (L + 1) // 2, device=wave.device)
+    check(lib.wm_wave_resample(ptr(wave), ptr(out), ptr(tmp), L, U, ptr(rs), 41, torch.cuda.current_stream().cuda_stream),
+          "wm_wave_resample")
+    return out
+
+
 def _attack(wave, attack, seed):
     name, _, param = (attack or "closed_loop").partition("-")
     if name in ("closed_loop", "no", ""):
@@ -64,6 +91,10 @@ def _attack(wave, attack, seed):
         return ops.wave_attack(wave, jitter=int(param) if param else 1000, seed=seed)
     if name == "requantization":                                          # :85-96 (PCM_U8 round trip)
         return ops.wave_attack(wave, requantize=True)
+    if name in ("low_pass", "lowpass", "low_pass_filter"):                # audio_test.py:637 -> audio_attack.py:21-30
+        return wave_lowpass(wave)
+    if name == "resampling":                                              # audio_test.py:644 -> audio_attack.py:71-83
+        return wave_resample(wave)
     raise NotImplementedError(f"attack '{name}' is a CPU tool of audio_attack.py outside the MI355X path (DESIGN.md, out of scope)")
 
 

@@ -174,6 +174,12 @@ int wm_stft255_tiles(const float* wave, int64_t L, int32_t U, float* tiles, floa
 int wm_istft255_stitch(const float* tiles, int32_t n_tiles, int32_t last_len, int32_t U, float* wave, int64_t L,
                        float out_scale, void* stream);
 int wm_wave_attack(const WmWaveAttack* a, const float* wave, float* out, int64_t L, int32_t U, float* power, void* stream);
+/* Whole-utterance 'low_pass' (audio_test.py:637 -> audio_attack.py:21-30: butter(8, 0.5) + filtfilt as two 128-tap FIR passes,
+ * lp_h = taps | steady-state tails as in WmAttack; tmp: [U, L + 54] floats) and 'resampling' (:644 -> :71-83, 16k -> 8k -> 16k
+ * with the 41-tap half-band filter rs_h, scipy resample_poly conventions: the librosa kernel is parity-unpinned; tmp: [U,
+ * ceil(L / 2)] floats) on [U, L] waveforms of any length; out: [U, L].                                                    */
+int wm_wave_lowpass(const float* wave, float* out, float* tmp, int64_t L, int32_t U, const float* lp_h, int32_t lp_n, void* stream);
+int wm_wave_resample(const float* wave, float* out, float* tmp, int64_t L, int32_t U, const float* rs_h, int32_t rs_n, void* stream);
 
 /* ---- in-graph STFT round trip — torch.istft / torch.stft with n_fft=255, hop 63, rectangular
  * window, center/reflect (model.py:2458,2463).  spec: [B,2,128,128] (re|im planes), wave: [B,8002] */

@@ -115,6 +115,19 @@ def test_wave_attack_echo_jitter_requantization(wm):
         assert wm.evaluate._attack(w.cuda(), name, 1).shape == (1, L)
 
 
+@pytest.mark.parametrize("L", [30011, 160000, 64, 801])
+def test_whole_utterance_lowpass_and_resampling(wm, L):
+    """'low_pass' (audio_test.py:637) and 'resampling' (:644) of the evaluation loop on rows of any length against the
+    oracle (scipy-pinned filtfilt / resample_poly restatements), two utterances at once."""
+    from oracle import attacks as A
+    w = torch.stack([torch.as_tensor(chirp_wave(L, f"lp{L}a"), dtype=torch.float32),
+                     torch.as_tensor(chirp_wave(L, f"lp{L}b"), dtype=torch.float32) * 0.5])
+    lp = wm.evaluate._attack(w.cuda(), "low_pass", 0)
+    assert rel(lp, A.low_pass(w.numpy())) <= 2e-5
+    rs = wm.evaluate._attack(w.cuda(), "resampling", 0)
+    assert rs.shape == (2, L) and rel(rs, A.resampling(w.numpy())) <= 2e-5
+
+
 def test_signaltonoise(wm):
     a = torch.as_tensor(chirp_wave(5000, "snr"), dtype=torch.float32) + 0.01
     assert abs(wm.evaluate.signaltonoise(a.cuda()) - E.signaltonoise(a.numpy())) < 1e-3
