@@ -87,6 +87,10 @@ _SIGS = {
     "wm_stft255_tables": [c_f, c_f],
     "wm_wave_lowpass": [c_f, c_f, c_f, c_i64, c_i32, c_f, c_i32, c_f],
     "wm_wave_resample": [c_f, c_f, c_f, c_i64, c_i32, c_f, c_i32, c_f],
+    "wm_pv_frames": [c_i64],
+    "wm_pv_steps": [c_i64, C.c_double],
+    "wm_time_stretch": [c_f, c_i64, c_i32, C.c_double, c_f, c_f, c_f, c_f, c_i64, c_f],
+    "wm_sinc_resample": [c_f, c_i64, c_i32, C.c_double, c_f, c_f, c_i32, c_i32, c_f, c_i64, c_f],
     "wm_istft255_fwd": [c_f, c_f, c_f, c_i32, c_f],
     "wm_stft255_fwd": [c_f, c_f, c_f, c_i32, c_f],
     "wm_istft255_bwd": [c_f, c_f, c_f, c_i32, c_f],

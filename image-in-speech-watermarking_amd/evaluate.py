@@ -77,6 +77,60 @@ def wave_resample(wave):
     return out
 
 
+def time_stretch(wave, rate, length=None):
+    """librosa.effects.time_stretch(y, rate) on [U, L] waveforms: phase vocoder (n_fft 2048, hop 512, Hann); output length
+    round(L / rate) unless `length` is given.  librosa semantics restated: parity unpinned."""
+    from ._lib import check, lib, ptr
+    wave = wave.contiguous().float()
+    U, L = wave.shape
+    T, Ts = int(lib.wm_pv_frames(L)), int(lib.wm_pv_steps(L, float(rate)))
+    Lout = int(round(L / rate)) if length is None else int(length)
+    spec = torch.empty(U, 1025, T + 2, 2, device=wave.device)
+    st = torch.empty(U, 1025, Ts, 2, device=wave.device)
+    frames = torch.empty(U, Ts, 2048, device=wave.device)
+    out = torch.empty(U, Lout, device=wave.device)
+    check(lib.wm_time_stretch(ptr(wave), L, U, float(rate), ptr(spec), ptr(st), ptr(frames), ptr(out), Lout,
+                              torch.cuda.current_stream().cuda_stream), "wm_time_stretch")
+    return out
+
+
+_sinc_tables = {}
+
+
+def _kaiser_best(device):
+    """resampy 'kaiser_best' half filter and its forward differences (64 zero crossings x 512 samples), built with numpy."""
+    key = str(device)
+    if key not in _sinc_tables:
+        import numpy as np
+        bits, zeros, rolloff, beta = 512, 64, 0.9475937167399596, 14.769656459379492
+        n = bits * zeros
+        t = np.linspace(0, zeros, num=n + 1, endpoint=True)
+        win = (rolloff * np.sinc(rolloff * t) * np.kaiser(2 * n + 1, beta)[n:]).astype(np.float32)
+        delta = np.zeros_like(win)
+        delta[:-1] = np.diff(win)
+        _sinc_tables[key] = (torch.from_numpy(win).to(device), torch.from_numpy(delta).to(device), bits)
+    return _sinc_tables[key]
+
+
+def pitch_shift(wave, n_steps=-6.0, bins_per_octave=12):
+    """librosa.effects.pitch_shift(y, sr, n_steps) on [U, L] waveforms: time stretch by 2^(-n_steps / 12), band-limited
+    resampling by the same ratio, length fixed to L.  Parity unpinned (librosa / resampy are not in the reference tree)."""
+    from ._lib import check, lib, ptr
+    import math
+    wave = wave.contiguous().float()
+    U, L = wave.shape
+    rate = 2.0 ** (-float(n_steps) / bins_per_octave)
+    ys = time_stretch(wave, rate)
+    win, delta, bits = _kaiser_best(wave.device)
+    out = torch.empty(U, L, device=wave.device)                  # fix_length(resampled, L): zero beyond ceil(len * rate)
+    n = int(math.ceil(ys.shape[1] * rate))
+    check(lib.wm_sinc_resample(ptr(ys), ys.shape[1], U, rate, ptr(win), ptr(delta), win.numel(), bits, ptr(out), L,
+                               torch.cuda.current_stream().cuda_stream), "wm_sinc_resample")
+    if n < L:
+        out[:, n:] = 0
+    return out
+
+
 def _attack(wave, attack, seed):
     name, _, param = (attack or "closed_loop").partition("-")
     if name in ("closed_loop", "no", ""):
@@ -95,6 +149,10 @@ def _attack(wave, attack, seed):
         return wave_lowpass(wave)
     if name == "resampling":                                              # audio_test.py:644 -> audio_attack.py:71-83
         return wave_resample(wave)
+    if name == "time_scaling":                                            # audio_test.py:654 -> audio_attack.py:195-231
+        return time_stretch(wave, float(param))
+    if name == "pitch_scaling":                                           # audio_test.py:656 -> audio_attack.py:233-239
+        return pitch_shift(wave, -6.0)
     raise NotImplementedError(f"attack '{name}' is a CPU tool of audio_attack.py outside the MI355X path (DESIGN.md, out of scope)")
 
 

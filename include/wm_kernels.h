@@ -180,6 +180,19 @@ int wm_wave_attack(const WmWaveAttack* a, const float* wave, float* out, int64_t
  * ceil(L / 2)] floats) on [U, L] waveforms of any length; out: [U, L].                                                    */
 int wm_wave_lowpass(const float* wave, float* out, float* tmp, int64_t L, int32_t U, const float* lp_h, int32_t lp_n, void* stream);
 int wm_wave_resample(const float* wave, float* out, float* tmp, int64_t L, int32_t U, const float* rs_h, int32_t rs_n, void* stream);
+/* Phase-vocoder attacks (audio_attack.py:195-231 time_scaling = librosa.effects.time_stretch, :233-239 pitch_scaling =
+ * librosa.effects.pitch_shift; librosa's published algorithm restated, PARITY UNPINNED): wm_time_stretch = STFT(2048 / 512,
+ * Hann, reflect) -> phase vocoder at `rate` -> inverse STFT of length Lout (= round(L / rate) for time_scaling).  Caller-owned
+ * work buffers: spec [U, 1025, wm_pv_frames(L) + 2] complex64, stretched [U, 1025, wm_pv_steps(L, rate)] complex64, frames
+ * [U, wm_pv_steps(L, rate), 2048] floats.  wm_sinc_resample: band-limited interpolation by `ratio` (= target / source rate)
+ * from a half filter table `win` and its forward differences `delta` of nwin entries, `precision` table samples per zero
+ * crossing (resampy's 'kaiser_best' layout: 64 crossings x 512), out[t] for t < Lout.                                        */
+int32_t wm_pv_frames(int64_t L);
+int32_t wm_pv_steps(int64_t L, double rate);
+int wm_time_stretch(const float* wave, int64_t L, int32_t U, double rate, void* spec, void* stretched, float* frames, float* out,
+                    int64_t Lout, void* stream);
+int wm_sinc_resample(const float* in, int64_t Lin, int32_t U, double ratio, const float* win, const float* delta, int32_t nwin,
+                     int32_t precision, float* out, int64_t Lout, void* stream);
 
 /* ---- in-graph STFT round trip — torch.istft / torch.stft with n_fft=255, hop 63, rectangular
  * window, center/reflect (model.py:2458,2463).  spec: [B,2,128,128] (re|im planes), wave: [B,8002] */

@@ -128,6 +128,46 @@ def test_whole_utterance_lowpass_and_resampling(wm, L):
     assert rs.shape == (2, L) and rel(rs, A.resampling(w.numpy())) <= 2e-5
 
 
+@pytest.mark.parametrize("rate", [0.8, 1.1, 1.2])
+def test_time_scaling_matches_vocoder_oracle(wm, rate):
+    """'time_scaling-<rate>' (audio_test.py:654): the device phase vocoder against the numpy restatement of librosa's
+    algorithm (oracle/vocoder.py; librosa itself is absent: PARITY UNPINNED).  The phase recursion amplifies last-bit
+    differences of atan2 over ~100 frames, hence 2e-3 of full scale."""
+    from oracle import vocoder as V
+    L = 40000
+    w = torch.stack([torch.as_tensor(chirp_wave(L, "ts_a"), dtype=torch.float32),
+                     torch.as_tensor(chirp_wave(L, "ts_b"), dtype=torch.float32) * 0.7])
+    out = wm.evaluate._attack(w.cuda(), f"time_scaling-{rate}", 0)
+    assert out.shape == (2, int(round(L / rate)))
+    for u in range(2):
+        assert rel(out[u], V.time_stretch(w[u].numpy(), rate)) <= 2e-3, (u, rel(out[u], V.time_stretch(w[u].numpy(), rate)))
+    # rate 1 rebuilds the signal up to the float32 phase recursion (as librosa's does): close to the identity on a tone
+    t = torch.arange(L) / 16000.0
+    tone = (0.5 * torch.sin(2 * np.pi * 500.0 * t)).reshape(1, L)
+    same = wm.evaluate.time_stretch(tone.cuda(), 1.0)
+    assert rel(same[0, 2048:-2048], tone[0, 2048:-2048]) <= 2e-2
+
+
+def test_pitch_scaling_matches_vocoder_oracle(wm):
+    """'pitch_scaling' (audio_test.py:656: n_steps = -6): stretch + band-limited resampling + length fix vs the oracle; the
+    resampler alone against the oracle's resampy restatement for an up- and a down-sampling ratio."""
+    from oracle import vocoder as V
+    L = 24000
+    w = torch.as_tensor(chirp_wave(L, "ps"), dtype=torch.float32).reshape(1, L)
+    out = wm.evaluate._attack(w.cuda(), "pitch_scaling", 0)
+    assert out.shape == (1, L)
+    assert rel(out[0], V.pitch_shift(w[0].numpy(), -6)) <= 3e-3
+    win, delta, bits = wm.evaluate._kaiser_best(torch.device("cuda"))
+    for ratio in (1.41421356, 0.7):
+        n = int(np.ceil(6000 * ratio))
+        o = torch.empty(1, n, device="cuda")
+        x = w[:, :6000].contiguous().cuda()
+        L_ = importlib.import_module("image-in-speech-watermarking_amd._lib")
+        L_.check(wm.lib.wm_sinc_resample(L_.ptr(x), 6000, 1, ratio, L_.ptr(win), L_.ptr(delta), win.numel(),
+                                         bits, L_.ptr(o), n, torch.cuda.current_stream().cuda_stream), "sinc")
+        assert rel(o[0], V.sinc_resample(w[0, :6000].numpy(), ratio, n)) <= 1e-5, ratio
+
+
 def test_signaltonoise(wm):
     a = torch.as_tensor(chirp_wave(5000, "snr"), dtype=torch.float32) + 0.01
     assert abs(wm.evaluate.signaltonoise(a.cuda()) - E.signaltonoise(a.numpy())) < 1e-3
