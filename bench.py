@@ -34,10 +34,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=96,
+    ap.add_argument("--batch", type=int, default=192,
                     help="tiles per GPU.  The per-device batch is free (SURVEY 8: the reference script hard-codes 24, its CLI default "
-                         "is 4); 96 = 4 x 24 is where one MI355X leaves the latency-bound regime (B=24: ~1.5 workgroups per CU and "
-                         "launch).  The line also reports the B=24 rate (reference_batch) measured in the same run.")
+                         "is 4).  192 = 8 x 24 (about 40 GB of the 288 GB): at B=24 a launch puts ~1.5 workgroups on each CU and the "
+                         "step is latency-bound; the rate rises 0.86 -> 1.29 -> 1.35 -> 1.38 k audio-s/s over B = 24 / 96 / 192 / 256. "
+                         "The line also reports the B=24 rate (reference_batch) measured in the same run.")
     ap.add_argument("--no-reference-batch", action="store_true", help="skip the extra B=24 measurement")
     ap.add_argument("--attack", default="full", choices=["full", "none"],
                     help="full: BASELINE config 3 (resample + AWGN 20 dB + low-pass + x0.8 between iSTFT and STFT, extractor reads the "

@@ -187,10 +187,10 @@ __device__ __forceinline__ void split8(const float4& x0, const float4& x1, bf16x
 
 // One wave = 32 blocks (1024 samples) of the row; e has zeros from N up to NBLK * 32 (the caller pads).  J = 128.
 template <bool CAUSAL>
-__device__ __forceinline__ void fir_mfma(const float* e, float* y, const __bf16* __restrict__ tab, const float* tail, int N,
-                                         float edge, int tid) {
+__device__ __forceinline__ void fir_mfma(const float* e, float* y, const __bf16* tab, const float* tail, int N, float edge,
+                                         int tid) {
   const int lane = tid & 63, wv = tid >> 6, r = lane & 31, hh = lane >> 5;
-  const __bf16* t = tab + (CAUSAL ? 0 : 2 * FIR_KS * 512) + lane * 8;
+  const __bf16* t = tab + (CAUSAL ? 0 : 2 * FIR_KS * 512) + lane * 8;   // (the LDS copy the kernel made at its start)
   bf16x8 Bh[FIR_KS], Bl[FIR_KS];
 #pragma unroll
   for (int ks = 0; ks < FIR_KS; ++ks) {
@@ -253,11 +253,13 @@ __global__ __launch_bounds__(256) void fir_table_kernel(const float* __restrict_
 __device__ __forceinline__ void gauss4(uint64_t seed, uint64_t step, uint32_t row, uint32_t blk, float z[4]) {
   uint32_t r[4];
   philox4x32(blk, row, (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  // Box-Muller on the hardware transcendentals (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32 take turns): ~1e-6 of the libm
+  // values, a quarter of their instructions; the stream is defined by THIS function (wm_awgn_noise replays it)
   const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]), u3 = u01(r[3]);
-  const float m0 = sqrtf(-2.0f * logf(u0)), m1 = sqrtf(-2.0f * logf(u2));
-  float s, c;
-  sincospif(2.0f * u1, &s, &c); z[0] = m0 * c; z[1] = m0 * s;
-  sincospif(2.0f * u3, &s, &c); z[2] = m1 * c; z[3] = m1 * s;
+  const float m0 = __builtin_amdgcn_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(u0));     // -2 ln 2 log2(u)
+  const float m1 = __builtin_amdgcn_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(u2));
+  z[0] = m0 * __builtin_amdgcn_cosf(u1); z[1] = m0 * __builtin_amdgcn_sinf(u1);
+  z[2] = m1 * __builtin_amdgcn_cosf(u3); z[3] = m1 * __builtin_amdgcn_sinf(u3);
 }
 
 // jittering_2: the j-th zeroed position of a row; its own Philox stream (key differs from the AWGN stream's)
@@ -267,6 +269,17 @@ __device__ __forceinline__ int jitter_index(uint64_t seed, uint64_t step, uint32
   return (int)(((uint64_t)r[0] * (uint64_t)L) >> 32);
 }
 
+// Copies the MFMA operand image of the low-pass taps (40 KB) from global memory into LDS at the start of a kernel: the two FIR
+// passes then take their B fragments from LDS instead of waiting for 20 L2 loads each.  The first barrier of the kernel
+// orders the copy.  Returns NULL when the scalar path is to be used.
+__device__ __forceinline__ const __bf16* stage_fir_table(const WmAttack& a, int J, __bf16* dst, int tid) {
+  if (!(a.flags & 4) || !a.lp_mfma || J != FIR_J) return nullptr;
+  const uint4* src = static_cast<const uint4*>(a.lp_mfma);
+  uint4* d = reinterpret_cast<uint4*>(dst);
+  for (int i = tid; i < FIR_TAB / 8; i += NT) d[i] = src[i];
+  return dst;
+}
+
 __global__ __launch_bounds__(NT) void attack_fwd_kernel(const WmAttack a, const float* __restrict__ wave,
                                                         float* __restrict__ out, float* __restrict__ sigma_out,
                                                         int L) {
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(NT) void attack_fwd_kernel(const WmAttack a, const 
   float* A = sm; float* Bf = sm + BUF; float* hs = sm + 2 * BUF;   // hs: lp_h[J] | tail[J] | rs_h[41] | red[8]
   const int tid = threadIdx.x, row = blockIdx.x, J = a.lp_n;
   float* tails = hs + J; float* rsh = hs + 2 * J; float* red = rsh + 48;
-  const __bf16* tab = (a.lp_mfma && J == FIR_J) ? static_cast<const __bf16*>(a.lp_mfma) : nullptr;
+  const __bf16* tab = stage_fir_table(a, J, reinterpret_cast<__bf16*>(sm + 2 * BUF + 2 * 256 + 64), tid);
   if (a.flags & 4) for (int i = tid; i < 2 * J; i += NT) hs[i] = a.lp_h[i];
   if (a.flags & 1) for (int i = tid; i < 2 * RS_HALF + 1; i += NT) rsh[i] = a.rs_h[i];
   float* cur = A; float* oth = Bf;
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(NT) void attack_bwd_kernel(const WmAttack a, const 
   float* A = sm; float* Bf = sm + BUF; float* Cx = sm + 2 * BUF; float* hs = sm + 3 * BUF;
   const int tid = threadIdx.x, row = blockIdx.x, J = a.lp_n;
   float* tails = hs + J; float* rsh = hs + 2 * J; float* red = rsh + 48;
-  const __bf16* tab = (a.lp_mfma && J == FIR_J) ? static_cast<const __bf16*>(a.lp_mfma) : nullptr;
+  const __bf16* tab = stage_fir_table(a, J, reinterpret_cast<__bf16*>(sm + 3 * BUF + 2 * 256 + 64), tid);
   if (a.flags & 4) for (int i = tid; i < 2 * J; i += NT) hs[i] = a.lp_h[i];
   if (a.flags & 1) for (int i = tid; i < 2 * RS_HALF + 1; i += NT) rsh[i] = a.rs_h[i];
   const int Ld = (L + 1) / 2;
@@ -491,7 +504,7 @@ bool args_ok(const WmAttack* a, int B, int L) {
   if (a->flags & ~127) return false;
   return true;
 }
-size_t smem_bytes(int nbuf, int J) { return sizeof(float) * ((size_t)nbuf * BUF + 2 * J + 48 + 16); }
+size_t smem_bytes(int nbuf, int J) { (void)J; return sizeof(float) * ((size_t)nbuf * BUF + 2 * 256 + 64) + (size_t)FIR_TAB * 2; }
 
 }  // namespace
 
