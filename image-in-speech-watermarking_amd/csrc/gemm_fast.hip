@@ -715,7 +715,7 @@ int dispatch_tn(const WmGemm& g, hipStream_t st) {
 // Returns -1 when the launch does not fit the fast kernels (caller falls back to the generic kernel of gemm.hip).
 int wm_gemm_fast_bf16(const WmGemm& g, hipStream_t st) {
   if (g.defer) *g.defer = WmReduceJob{};                       // count 0 unless a split-K launch fills it in
-  if (g.mode != 1 || getenv("WM_NO_FAST")) return -1;
+  if (g.mode != 1) return -1;
   const int ea = g.a_bf16 ? 8 : 4, eb = g.b_bf16 ? 8 : 4;
   if (!g.a_kc && !g.b_kc && g.atomic_out && !g.a_op && !g.c_bf16) {          // weight gradient
     if ((g.M % ea) || (g.N % eb) || (g.lda % ea) || (g.ldb % eb) || g.M < ea || g.N < eb) return -1;

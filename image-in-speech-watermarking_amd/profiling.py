@@ -151,9 +151,43 @@ STFT_PATH = ("istft_fwd", "stft_fwd", "istft_bwd", "stft_bwd", "attack_fwd", "at
 # KernelTimer key -> __global__ functions (rocprofv3 kernel families) that carry it
 FAMILY_KERNELS = {"reduce_jobs": ["reduce_jobs_kernel"], "winattn_bwd_bf16": ["attn_bwd_fast_kernel"],
                   "winattn_fwd_bf16": ["attn_fwd_fast_kernel"], "layernorm_fwd": ["ln_fwd_kernel"],
-                  "layernorm_bwd": ["ln_bwd_kernel"], "istft_fwd": ["synth_kernel"], "stft_bwd": ["synth_kernel"],
-                  "stft_fwd": ["analysis_kernel"], "istft_bwd": ["analysis_kernel"], "attack_fwd": ["attack_fwd_kernel"],
+                  "layernorm_bwd": ["ln_bwd_kernel"], "istft_fwd": ["synth_mfma_kernel"], "stft_bwd": ["synth_mfma_kernel"],
+                  "stft_fwd": ["analysis_mfma_kernel"], "istft_bwd": ["analysis_mfma_kernel"], "attack_fwd": ["attack_fwd_kernel"],
                   "attack_bwd": ["attack_bwd_kernel"]}
+
+
+def time_stft_path(wm, batch, attack_cfg, reps=20):
+    """HIP-event time per launch of the six short kernels of the STFT / iSTFT / attack path (9-50 us each), each replayed
+    `reps` times from a captured graph on the launch stream: one event pair around a single 15 us launch measures mostly
+    the events (the eager pass of KernelTimer reads 8-12 us high for them; rocprofv3 agrees with this form)."""
+    B = int(batch)
+    dev = torch.device("cuda")
+    spec, wave = torch.randn(B, 2, 128, 128, device=dev), 0.1 * torch.randn(B, 8002, device=dev)
+    spec2, wave2 = torch.empty_like(spec), torch.empty_like(wave)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    fns = {"istft_fwd": lambda: ops.istft_fwd(spec, wave2, B), "stft_fwd": lambda: ops.stft_fwd(wave, spec2, B),
+           "istft_bwd": lambda: ops.istft_bwd(wave, spec2, B), "stft_bwd": lambda: ops.stft_bwd(spec, wave2, B)}
+    if attack_cfg is not None:
+        out, sigma = wm.attacks.attack_forward(attack_cfg, wave, step)
+        fns["attack_fwd"] = lambda: wm.attacks.attack_forward(attack_cfg, wave, step, out=out, sigma=sigma)
+        fns["attack_bwd"] = lambda: wm.attacks.attack_backward(attack_cfg, wave, wave2, sigma, step, dwave=out)
+    res = {}
+    for name, fn in fns.items():
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        res[name] = s.elapsed_time(e) / reps * 1e-3                     # seconds per launch
+    return res
 
 
 def source_id():
