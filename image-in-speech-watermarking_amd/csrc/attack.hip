@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int NT = 512;
+constexpr int NT = 1024;               // 16 waves: the LDS-latency-bound stages (resampler, extension, reductions) overlap better
 constexpr int PADLEN = 27;                 // scipy filtfilt default: 3 * max(len(a), len(b)) = 3 * 9
 constexpr int RS_HALF = 20;                // resample_poly half length for rate 2
 constexpr int NBLK = 252, LDB = 36;        // 252 blocks of 32 samples (8064 >= 8002 + 2 * 27), 36 words apart
@@ -190,6 +190,7 @@ template <bool CAUSAL>
 __device__ __forceinline__ void fir_mfma(const float* e, float* y, const __bf16* tab, const float* tail, int N, float edge,
                                          int tid) {
   const int lane = tid & 63, wv = tid >> 6, r = lane & 31, hh = lane >> 5;
+  if (wv >= (NBLK + 31) / 32) return;                         // 8 row tiles of 32 blocks: waves 8 .. 15 sit this stage out
   const __bf16* t = tab + (CAUSAL ? 0 : 2 * FIR_KS * 512) + lane * 8;   // (the LDS copy the kernel made at its start)
   bf16x8 Bh[FIR_KS], Bl[FIR_KS];
 #pragma unroll
