@@ -159,8 +159,9 @@ def cpu_baseline(attacked, batch=4, steps=3):
                                       f"median {med:.3f} s/step", "host_cpus": os.cpu_count()}
 
 
-def ber_parity(wm, net, x, msg, tiles=4):
-    """Decoder BER parity (second half of BASELINE's metric): BER = mean(|round(clip(wm, 0, 1)) - bits|)
+def cpu_baseline_parity(wm, net, x, msg, tiles=4):
+    """Second part of the cpu_baseline leg — the oracle as the CHECKER, not as anything measured or shipped.
+    Decoder BER parity (second half of BASELINE's metric): BER = mean(|round(clip(wm, 0, 1)) - bits|)
     (hidden/test_model.py:60-64) of the extractor output without attack and after the full attack stack, for the HIP path
     in the benched mode and in fp32 parity mode, against the fp32 CPU oracle on identical weights and inputs; the AWGN
     realisation of the HIP kernels (wm_awgn_noise) is replayed through the oracle's attack chain.  Eval mode, `tiles`
@@ -262,7 +263,7 @@ def main():
 
     ber = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.clip_seconds == 1:
-        ber = ber_parity(wm, net, x, msg)                        # before any optimiser step: weights = the synthetic init
+        ber = cpu_baseline_parity(wm, net, x, msg)               # before any optimiser step: weights = the synthetic init
 
     step = wm.TrainStep(net, opt, a.batch, attack=attack, extract_from=extract_from, use_graph=not a.no_graph,
                         segmented=a.segmented)
