@@ -20,24 +20,56 @@ constexpr int TC = 64;             // channels per workgroup
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-// a = x Phi(x), g = Phi(x) + x phi(x) for two values (same Abramowitz-Stegun form as gelu_f; packed arithmetic)
-__device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& a, f32x2& g) {
-  f32x2 e, t;
-  e.x = __expf(-0.5f * x.x * x.x);
-  e.y = __expf(-0.5f * x.y * x.y);
-  const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
-  const f32x2 den = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
-  t.x = __builtin_amdgcn_rcpf(den.x);                           // v_rcp_f32 (1 ulp), not the IEEE division sequence
-  t.y = __builtin_amdgcn_rcpf(den.y);
-  f32x2 p = t * 1.061405429f - 1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t - 0.284496736f;
-  p = p * t + 0.254829592f;
-  const f32x2 q = p * t * e * 0.5f;                           // Phi(-|x|)
-  const f32x2 cdf = {x.x >= 0.f ? 1.0f - q.x : q.x, x.y >= 0.f ? 1.0f - q.y : q.y};
-  a = x * cdf;
-  g = cdf + x * e * 0.39894228040143268f;
-}
+// a = x Phi(x), g = Phi(x) + x phi(x) for two values.
+// ST = float (parity mode): the Abramowitz-Stegun form of gelu_f in packed arithmetic (|err| <= 1.5e-7).
+// ST = __bf16: both results are rounded to bf16 on their way out (2^-9 relative), and the exp / rcp pair is what
+// makes these kernels VALU-bound, so Phi(x) - 1/2 = z Q(z^2) and gelu'(x) - 1/2 = z G(z^2) are evaluated as degree-7
+// polynomials in z^2 on z = clamp(x, -4, 4) (minimax fits, Q pinned to Phi(4) = 1 so that x >= 4 gives x and x <= -4
+// gives 0): |Phi err| <= 3.4e-5, |gelu err| <= 1.4e-4, |gelu' err| <= 2.9e-4 in fp32 Horner form, packed FMAs only.
+template <typename ST> struct Gelu;
+template <> struct Gelu<float> {
+  static __device__ __forceinline__ void pair(f32x2 x, f32x2& a, f32x2& g) {
+    f32x2 e, t;
+    e.x = __expf(-0.5f * x.x * x.x);
+    e.y = __expf(-0.5f * x.y * x.y);
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const f32x2 den = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
+    t.x = __builtin_amdgcn_rcpf(den.x);                           // v_rcp_f32 (1 ulp), not the IEEE division sequence
+    t.y = __builtin_amdgcn_rcpf(den.y);
+    f32x2 p = t * 1.061405429f - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const f32x2 q = p * t * e * 0.5f;                           // Phi(-|x|)
+    const f32x2 cdf = {x.x >= 0.f ? 1.0f - q.x : q.x, x.y >= 0.f ? 1.0f - q.y : q.y};
+    a = x * cdf;
+    g = cdf + x * e * 0.39894228040143268f;
+  }
+};
+template <> struct Gelu<__bf16> {
+  static __device__ __forceinline__ void pair(f32x2 x, f32x2& a, f32x2& g) {
+    const f32x2 z = {__builtin_amdgcn_fmed3f(x.x, -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x.y, -4.0f, 4.0f)};
+    const f32x2 s = z * z;
+    f32x2 q = s * -1.275896465e-09f + 1.043209509e-07f;
+    q = q * s - 3.706793989e-06f;
+    q = q * s + 7.615712969e-05f;
+    q = q * s - 1.020840068e-03f;
+    q = q * s + 9.580739327e-03f;
+    q = q * s - 6.606320376e-02f;
+    q = q * s + 3.988051945e-01f;
+    f32x2 d = s * -1.641966869e-08f + 1.213799991e-06f;
+    d = d * s - 3.845945104e-05f;
+    d = d * s + 6.876443834e-04f;
+    d = d * s - 7.687437958e-03f;
+    d = d * s + 5.591482390e-02f;
+    d = d * s - 2.620298507e-01f;
+    d = d * s + 7.967216468e-01f;
+    a = x * (z * q + 0.5f);
+    g = z * d + 0.5f;
+  }
+};
+template <typename ST>
+__device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& a, f32x2& g) { Gelu<ST>::pair(x, a, g); }
 
 template <typename ST> struct Chunk;                          // one 16-byte global chunk
 template <> struct Chunk<__bf16> {
@@ -90,6 +122,16 @@ __device__ __forceinline__ void halo_load(u32x4 (&c)[Halo<ST>::NL], const ST* __
     c[k] = v;
   }
 }
+// raw copy of the staged halo into an LDS image of the storage type (no conversion: the backward keeps dh2 as it lies)
+template <typename ST>
+__device__ __forceinline__ void halo_to_lds_raw(ST* tile, const u32x4 (&c)[Halo<ST>::NL], int tid) {
+  typedef Halo<ST> H;
+#pragma unroll
+  for (int k = 0; k < H::NL; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < H::NCH) *reinterpret_cast<u32x4*>(tile + idx * H::NE) = c[k];
+  }
+}
 template <typename ST, bool GELU>
 __device__ __forceinline__ void halo_to_lds(float* tile, const u32x4 (&c)[Halo<ST>::NL], int tid) {
   typedef Halo<ST> H;
@@ -103,7 +145,7 @@ __device__ __forceinline__ void halo_to_lds(float* tile, const u32x4 (&c)[Halo<S
 #pragma unroll
         for (int i = 0; i < H::NE; i += 2) {
           f32x2 a, g;
-          gelu_pair((f32x2){f[i], f[i + 1]}, a, g);
+          gelu_pair<ST>((f32x2){f[i], f[i + 1]}, a, g);
           f[i] = a.x;
           f[i + 1] = a.y;
         }
@@ -168,7 +210,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ST* __restrict__ 
     // those launches VALU-bound
     if (a2 || g2) {
       f32x2 av, gv;
-      gelu_pair(o, av, gv);
+      gelu_pair<ST>(o, av, gv);
       if (a2) *reinterpret_cast<raw*>(a2 + off) = Pair<ST>::down(av);
       if (g2) *reinterpret_cast<raw*>(g2 + off) = Pair<ST>::down(gv);
     }
@@ -202,7 +244,8 @@ __device__ __forceinline__ void cols_load(u32x4 (&c)[NLD], const ST* __restrict_
     c[k] = v;
   }
 }
-// gelu of the staged columns into their ring slots
+// gelu of the staged columns into their ring slots (fp32 in LDS: a bf16 ring would let five instead of three workgroups
+// share a CU but was measured at 3 % for one more rounding of gelu(h1); the kernel is bound by its VALU instruction count)
 template <typename ST, int NCOL, int NLD>
 __device__ __forceinline__ void cols_to_ring(float* ring, const u32x4 (&c)[NLD], int gx0, int tid) {
   typedef Cols<ST, NCOL> H;
@@ -218,7 +261,7 @@ __device__ __forceinline__ void cols_to_ring(float* ring, const u32x4 (&c)[NLD],
 #pragma unroll
       for (int i = 0; i < H::NE; i += 2) {
         f32x2 a, g;
-        gelu_pair((f32x2){f[i], f[i + 1]}, a, g);
+        gelu_pair<ST>((f32x2){f[i], f[i + 1]}, a, g);
         f[i] = a.x;
         f[i + 1] = a.y;
       }
@@ -238,8 +281,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restr
   __shared__ __attribute__((aligned(16))) float wl[10 * TC];
   typedef typename Pair<ST>::raw raw;
   const int tid = threadIdx.x, nt = hw / TP;
-  const int b = blockIdx.x / nt, ty = blockIdx.x % nt;
-  const int cbase = blockIdx.y * TC;
+  const int b = blockIdx.y / nt, ty = blockIdx.y % nt;     // channel chunks of one strip are neighbours in dispatch order
+  const int cbase = blockIdx.x * TC;
   const int c2 = tid & 31, py = tid >> 5;
   u32x4 creg[Cols<ST, TP>::NL];
   {
@@ -261,17 +304,18 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restr
     __syncthreads();
     if (tx + 1 < nt) cols_load<ST, TP>(creg, h1, b, ty, (tx + 1) * TP + 1, hw, Ch, cbase, tid);
     const int s0 = tx * TP;                                   // ring slot of halo column lx: (s0 + lx) & 15
+    auto at = [&](int dy, int x) {
+      return *reinterpret_cast<const f32x2*>(ring + ((py + dy) * RING + ((s0 + x) & (RING - 1))) * TC + 2 * c2);
+    };
     f32x2 col[3][3];                                          // col[x % 3][dy]
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-        col[x][dy] = *reinterpret_cast<const f32x2*>(ring + ((py + dy) * RING + ((s0 + x) & (RING - 1))) * TC + 2 * c2);
+      for (int dy = 0; dy < 3; ++dy) col[x][dy] = at(dy, x);
 #pragma unroll
     for (int px = 0; px < TP; ++px) {
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-        col[(px + 2) % 3][dy] = *reinterpret_cast<const f32x2*>(ring + ((py + dy) * RING + ((s0 + px + 2) & (RING - 1))) * TC + 2 * c2);
+      for (int dy = 0; dy < 3; ++dy) col[(px + 2) % 3][dy] = at(dy, px + 2);
       f32x2 o = br;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
@@ -281,7 +325,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restr
       if (h2) *reinterpret_cast<raw*>(h2 + off) = Pair<ST>::down(o);
       if (a2 || g2) {
         f32x2 av, gv;
-        gelu_pair(o, av, gv);
+        gelu_pair<ST>(o, av, gv);
         if (a2) *reinterpret_cast<raw*>(a2 + off) = Pair<ST>::down(av);
         if (g2) *reinterpret_cast<raw*>(g2 + off) = Pair<ST>::down(gv);
       }
@@ -298,23 +342,25 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restr
 // over the strip; at the end they are reduced over the 8 tile rows and either stored to `part` (one slot per
 // workgroup, summed by dwconv_grad_reduce_kernel) or added with global atomics when there is no scratch buffer.
 template <typename ST>
-__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ST* __restrict__ h1, const ST* __restrict__ dh2,
+__global__ __launch_bounds__(256, sizeof(ST) == 2 ? 4 : 1) void dwconv_bwd_kernel(const ST* __restrict__ h1, const ST* __restrict__ dh2,
                                                          const float* __restrict__ w, ST* __restrict__ dh1,
                                                          float* __restrict__ dw, float* __restrict__ db,
                                                          float* __restrict__ part, int B, int hw, int Ch) {
-  __shared__ __attribute__((aligned(16))) float tg[HP * HP * TC];      // dh2 with halo
+  // dh2 with halo, in the storage type (bf16: 12.5 KB); the same bytes take the 4 x 64 x 10 partial sums at the end
+  __shared__ __attribute__((aligned(16))) float tgf[(HP * HP * TC * sizeof(ST) > 4 * TC * 10 * 4 ? HP * HP * TC * sizeof(ST) : 4 * TC * 10 * 4) / 4];
   __shared__ __attribute__((aligned(16))) float wl[10 * TC];
+  ST* const tg = reinterpret_cast<ST*>(tgf);
   typedef typename Pair<ST>::raw raw;
   const int tid = threadIdx.x, nt = hw / TP;
-  const int b = blockIdx.x / nt, ty = blockIdx.x % nt;
-  const int cbase = blockIdx.y * TC;
+  const int b = blockIdx.y / nt, ty = blockIdx.y % nt;     // channel chunks of one strip are neighbours in dispatch order
+  const int cbase = blockIdx.x * TC;
   const int c2 = tid & 31, py = tid >> 5;
   u32x4 hreg[Halo<ST>::NL];
-  raw hn[TP], hc[TP];
+  raw hv[TP];                                                 // h1 of the current tile; each slot is refilled for the next tile once it is consumed
   halo_load<ST>(hreg, dh2, b, ty, 0, hw, Ch, cbase, tid);
   const int64_t strip0 = (((int64_t)b * hw + ty * TP + py) * hw) * Ch + cbase + 2 * c2;
 #pragma unroll
-  for (int px = 0; px < TP; ++px) hn[px] = *reinterpret_cast<const raw*>(h1 + strip0 + (int64_t)px * Ch);
+  for (int px = 0; px < TP; ++px) hv[px] = *reinterpret_cast<const raw*>(h1 + strip0 + (int64_t)px * Ch);
   stage_weights(wl, w, nullptr, cbase, tid);
   __syncthreads();
   f32x2 wr[9], aw[9], ab = {0.f, 0.f};
@@ -325,28 +371,23 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ST* __restrict__ 
   }
   for (int tx = 0; tx < nt; ++tx) {
     __syncthreads();
-    halo_to_lds<ST, false>(tg, hreg, tid);
-#pragma unroll
-    for (int px = 0; px < TP; ++px) hc[px] = hn[px];
+    halo_to_lds_raw<ST>(tg, hreg, tid);
     __syncthreads();
-    {                                                         // next tile's loads fly during this tile's arithmetic
-      const int txn = tx + 1 < nt ? tx + 1 : tx;
-      halo_load<ST>(hreg, dh2, b, ty, txn, hw, Ch, cbase, tid);
-#pragma unroll
-      for (int px = 0; px < TP; ++px) hn[px] = *reinterpret_cast<const raw*>(h1 + strip0 + (int64_t)(txn * TP + px) * Ch);
-    }
+    const int txn = tx + 1 < nt ? tx + 1 : tx;               // next tile's loads fly during this tile's arithmetic
+    halo_load<ST>(hreg, dh2, b, ty, txn, hw, Ch, cbase, tid);
     f32x2 col[3][3];                                          // col[x % 3][row]: dh2 at halo row py + row, halo column x
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr) col[x][rr] = *reinterpret_cast<const f32x2*>(tg + ((py + rr) * HP + x) * TC + 2 * c2);
+      for (int rr = 0; rr < 3; ++rr) col[x][rr] = Pair<ST>::up(*reinterpret_cast<const raw*>(tg + ((py + rr) * HP + x) * TC + 2 * c2));
 #pragma unroll
     for (int px = 0; px < TP; ++px) {
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr)
-        col[(px + 2) % 3][rr] = *reinterpret_cast<const f32x2*>(tg + ((py + rr) * HP + px + 2) * TC + 2 * c2);
+        col[(px + 2) % 3][rr] = Pair<ST>::up(*reinterpret_cast<const raw*>(tg + ((py + rr) * HP + px + 2) * TC + 2 * c2));
       f32x2 a1, gp;
-      gelu_pair(Pair<ST>::up(hc[px]), a1, gp);
+      gelu_pair<ST>(Pair<ST>::up(hv[px]), a1, gp);
+      hv[px] = *reinterpret_cast<const raw*>(h1 + strip0 + (int64_t)(txn * TP + px) * Ch);
       f32x2 o = {0.f, 0.f};
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
@@ -369,7 +410,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ST* __restrict__ 
   ab.x += __shfl_xor(ab.x, 32);
   ab.y += __shfl_xor(ab.y, 32);
   __syncthreads();
-  float* red = tg;                                            // [4 waves][64 channels][10]
+  float* red = tgf;                                           // [4 waves][64 channels][10]
   if ((tid & 63) < 32) {
     float* dst = red + ((tid >> 6) * TC + 2 * c2) * 10;
 #pragma unroll
@@ -381,7 +422,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ST* __restrict__ 
   for (int i = tid; i < TC * 10; i += 256) {
     const float s = red[i] + red[TC * 10 + i] + red[2 * TC * 10 + i] + red[3 * TC * 10 + i];
     const int c = i / 10, k = i - c * 10;
-    if (part) part[((int64_t)blockIdx.x * Ch + cbase) * 10 + i] = s;
+    if (part) part[((int64_t)blockIdx.y * Ch + cbase) * 10 + i] = s;
     else if (k < 9) atomicAdd(dw + (cbase + c) * 9 + k, s);
     else atomicAdd(db + cbase + c, s);
   }
@@ -420,10 +461,10 @@ extern "C" int wm_dwconv_fwd(const void* h1, const float* w, const float* b, voi
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (nt >= 2) {                                              // strips of two tiles and more: the ring saves up to a fifth of the first GELUs
     if (io_bf16)
-      hipLaunchKernelGGL(dwconv_fwd_strip_kernel<__bf16>, dim3(B * nt, Ch / TC), dim3(256), 0, st,
+      hipLaunchKernelGGL(dwconv_fwd_strip_kernel<__bf16>, dim3(Ch / TC, B * nt), dim3(256), 0, st,
                          static_cast<const __bf16*>(h1), w, b, static_cast<__bf16*>(h2), static_cast<__bf16*>(a2), static_cast<__bf16*>(g2), B, hw, Ch);
     else
-      hipLaunchKernelGGL(dwconv_fwd_strip_kernel<float>, dim3(B * nt, Ch / TC), dim3(256), 0, st,
+      hipLaunchKernelGGL(dwconv_fwd_strip_kernel<float>, dim3(Ch / TC, B * nt), dim3(256), 0, st,
                          static_cast<const float*>(h1), w, b, static_cast<float*>(h2), static_cast<float*>(a2), static_cast<float*>(g2), B, hw, Ch);
     WM_CHECK_LAUNCH();
     return WM_OK;
@@ -449,10 +490,10 @@ extern "C" int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, vo
   const int nt = hw / TP;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (io_bf16)
-    hipLaunchKernelGGL(dwconv_bwd_kernel<__bf16>, dim3(B * nt, Ch / TC), dim3(256), 0, st, static_cast<const __bf16*>(h1),
+    hipLaunchKernelGGL(dwconv_bwd_kernel<__bf16>, dim3(Ch / TC, B * nt), dim3(256), 0, st, static_cast<const __bf16*>(h1),
                        static_cast<const __bf16*>(dh2), w, static_cast<__bf16*>(dh1), dw, db, scratch, B, hw, Ch);
   else
-    hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(B * nt, Ch / TC), dim3(256), 0, st, static_cast<const float*>(h1),
+    hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(Ch / TC, B * nt), dim3(256), 0, st, static_cast<const float*>(h1),
                        static_cast<const float*>(dh2), w, static_cast<float*>(dh1), dw, db, scratch, B, hw, Ch);
   WM_CHECK_LAUNCH();
   if (defer) {                                                // two entries: dw [Ch][9], db [Ch] out of part[p][Ch][10]
