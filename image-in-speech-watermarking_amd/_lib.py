@@ -121,6 +121,11 @@ _SIGS = {
     "wm_batchnorm2d_bwd": [c_f] * 10 + [c_i32, c_i32, c_i32, c_i32, c_i32, c_fl, c_f],
     "wm_dropout": [c_f, c_f, c_i64, c_fl, c_u64, c_u64, c_f],
     "wm_mse_fwd_bwd": [c_f, c_f, c_i64, c_f, c_f, c_f, c_fl, c_f],
+    "wm_plane_fill": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_fl, c_f],
+    "wm_plane_sum": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_fl, c_f],
+    "wm_bce_logits_fwd_bwd": [c_f, c_i32, c_fl, c_f, c_f, c_fl, c_f],
+    "wm_linear_small_fwd": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_f],
+    "wm_linear_small_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_f],
 }
 EXPORTS = tuple(_SIGS)
 

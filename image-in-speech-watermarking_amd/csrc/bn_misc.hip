@@ -138,6 +138,81 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, c
   if (threadIdx.x == 0 && loss) atomicAdd(loss, s / (float)n);
 }
 
+// dst[b][c0 + l][:] = scale * v[b][l]  (message planes of the HiDDeN encoder, backward of the global average pool)
+__global__ __launch_bounds__(256) void plane_fill_kernel(const float* __restrict__ v, float* __restrict__ dst, int L, int Ctot,
+                                                         int c0, int HW, float scale) {
+  const int bl = blockIdx.x, b = bl / L, l = bl - b * L;
+  const float x = v[bl] * scale;
+  float* d = dst + ((int64_t)b * Ctot + c0 + l) * HW;
+  for (int i = threadIdx.x; i < HW; i += 256) d[i] = x;
+}
+// v[b][l] = scale * sum over the plane src[b][c0 + l][:]  (global average pool, backward of the message planes)
+__global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict__ src, float* __restrict__ v, int L, int Ctot,
+                                                        int c0, int HW, float scale) {
+  __shared__ float red[4];
+  const int bl = blockIdx.x, b = bl / L, l = bl - b * L;
+  const float* s = src + ((int64_t)b * Ctot + c0 + l) * HW;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) a += s[i];
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) v[bl] = a * scale;
+}
+// BCEWithLogitsLoss(x, target) with one target for all n logits: loss += mean(max(x, 0) - x t + log(1 + exp(-|x|)));
+// dx = gscale * (sigmoid(x) - t) / n
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, int n, float t, float* __restrict__ loss,
+                                                         float* __restrict__ dx, float gscale) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = x[i], e = __expf(-fabsf(v));
+    s += fmaxf(v, 0.f) - v * t + log1pf(e);
+    if (dx) {
+      const float sig = v >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+      dx[i] = gscale * (sig - t) / (float)n;
+    }
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, s / (float)n);
+}
+
+// Linear head of the discriminator (a few outputs on [M, K] pooled features): y[m][n] = x[m] . w[n] + b[n]
+__global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float* __restrict__ y, int M, int N,
+                                                               int K) {
+  __shared__ float red[4];
+  const int m = blockIdx.x / N, n = blockIdx.x - m * N;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) s += x[(int64_t)m * K + k] * w[(int64_t)n * K + k];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) y[blockIdx.x] = s + (b ? b[n] : 0.f);
+}
+// dx[m][k] = sum_n dy[m][n] w[n][k];  dw[n][k] += sum_m dy[m][n] x[m][k];  db[n] += sum_m dy[m][n]  (thread = one k)
+__global__ __launch_bounds__(256) void linear_small_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ w, float* __restrict__ dx,
+                                                               float* __restrict__ dw, float* __restrict__ db, int M, int N,
+                                                               int K) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < K) {
+    if (dx)
+      for (int m = 0; m < M; ++m) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dy[m * N + n] * w[(int64_t)n * K + k];
+        dx[(int64_t)m * K + k] = s;
+      }
+    if (dw)
+      for (int n = 0; n < N; ++n) {
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s += dy[m * N + n] * x[(int64_t)m * K + k];
+        dw[(int64_t)n * K + k] += s;
+      }
+  }
+  if (db && k < N) {
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dy[m * N + k];
+    db[k] += s;
+  }
+}
+
 inline unsigned ew_grid(int64_t total) {
   const int64_t b = (total + 255) / 256;
   return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -194,6 +269,48 @@ extern "C" int wm_mse_fwd_bwd(const float* a, const float* b, int64_t n, float* 
   if (!a || !b || n <= 0) return WM_EINVAL;
   hipLaunchKernelGGL(mse_kernel, dim3(ew_grid(n) > 512 ? 512 : ew_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, n,
                      loss, da, db, gscale);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int wm_plane_fill(const float* v, float* dst, int32_t B, int32_t L, int32_t Ctot, int32_t c0, int32_t HW, float scale,
+                             void* stream) {
+  if (!v || !dst || B <= 0 || L <= 0 || c0 < 0 || c0 + L > Ctot || HW <= 0) return WM_EINVAL;
+  hipLaunchKernelGGL(plane_fill_kernel, dim3(B * L), dim3(256), 0, static_cast<hipStream_t>(stream), v, dst, L, Ctot, c0, HW, scale);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int wm_plane_sum(const float* src, float* v, int32_t B, int32_t L, int32_t Ctot, int32_t c0, int32_t HW, float scale,
+                            void* stream) {
+  if (!src || !v || B <= 0 || L <= 0 || c0 < 0 || c0 + L > Ctot || HW <= 0) return WM_EINVAL;
+  hipLaunchKernelGGL(plane_sum_kernel, dim3(B * L), dim3(256), 0, static_cast<hipStream_t>(stream), src, v, L, Ctot, c0, HW, scale);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int wm_bce_logits_fwd_bwd(const float* logits, int32_t n, float target, float* loss, float* dlogits, float gscale,
+                                     void* stream) {
+  if (!logits || n <= 0 || (!loss && !dlogits)) return WM_EINVAL;
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), logits, n, target, loss, dlogits,
+                     gscale);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int wm_linear_small_fwd(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t N, int32_t K,
+                                   void* stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || (int64_t)M * N > 1 << 20) return WM_EINVAL;
+  hipLaunchKernelGGL(linear_small_fwd_kernel, dim3(M * N), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, b, y, M, N, K);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+extern "C" int wm_linear_small_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int32_t M,
+                                   int32_t N, int32_t K, void* stream) {
+  if (!dy || !x || !w || M <= 0 || N <= 0 || K <= 0 || N > K) return WM_EINVAL;
+  hipLaunchKernelGGL(linear_small_bwd_kernel, dim3((K + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), dy, x, w, dx,
+                     dw, db, M, N, K);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

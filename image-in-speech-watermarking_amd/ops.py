@@ -333,6 +333,30 @@ def mse_fwd_bwd(a, b, loss, da=None, db=None, gscale=1.0):
     check(lib.wm_mse_fwd_bwd(ptr(a), ptr(b), a.numel(), ptr(loss), ptr(da), ptr(db), gscale, _stream()), "wm_mse_fwd_bwd")
 
 
+def plane_fill(v, dst, B, L, Ctot, c0, HW, scale=1.0):
+    """dst[b, c0 + l, :] = scale * v[b, l]"""
+    check(lib.wm_plane_fill(ptr(v), ptr(dst), B, L, Ctot, c0, HW, float(scale), _stream()), "wm_plane_fill")
+
+
+def plane_sum(src, v, B, L, Ctot, c0, HW, scale=1.0):
+    """v[b, l] = scale * sum(src[b, c0 + l, :])"""
+    check(lib.wm_plane_sum(ptr(src), ptr(v), B, L, Ctot, c0, HW, float(scale), _stream()), "wm_plane_sum")
+
+
+def bce_logits_fwd_bwd(logits, target, loss, dlogits=None, gscale=1.0):
+    check(lib.wm_bce_logits_fwd_bwd(ptr(logits), logits.numel(), float(target), ptr(loss), ptr(dlogits), float(gscale), _stream()),
+          "wm_bce_logits_fwd_bwd")
+
+
+def linear_small_fwd(x, w, b, y):
+    check(lib.wm_linear_small_fwd(ptr(x), ptr(w), ptr(b), ptr(y), x.shape[0], w.shape[0], w.shape[1], _stream()), "wm_linear_small_fwd")
+
+
+def linear_small_bwd(dy, x, w, dx, dw, db):
+    check(lib.wm_linear_small_bwd(ptr(dy), ptr(x), ptr(w), ptr(dx), ptr(dw), ptr(db), x.shape[0], w.shape[0], w.shape[1], _stream()),
+          "wm_linear_small_bwd")
+
+
 def charbonnier_fwd_bwd(x, y, eps, loss, dx=None, dy=None, gscale=1.0):
     check(lib.wm_charbonnier_fwd_bwd(ptr(x), ptr(y), x.numel(), float(eps), ptr(loss), ptr(dx), ptr(dy), float(gscale), _stream()),
           "wm_charbonnier_fwd_bwd")

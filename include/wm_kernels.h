@@ -282,6 +282,29 @@ int wm_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint
 int wm_mse_fwd_bwd(const float* a, const float* b, int64_t n, float* loss, float* da, float* db, float gscale,
                    void* stream);
 
+/* ---- HiDDeN encoder / discriminator / adversarial loss.  hidden/options.py:19-50 configures them (encoder_blocks,
+ * encoder_channels, discriminator_blocks, discriminator_channels, adversarial_loss) and hidden/utils.py:85-108 saves and
+ * restores `encoder_decoder` / `discriminator`, but the modules themselves are absent from the reference tree; these
+ * entry points serve the architecture of the HiDDeN paper (Zhu et al. 2018, section 3) built from ConvBNRelu blocks:
+ *   wm_plane_fill   dst[b][c0 + l][:] = scale * v[b][l]: the message replicated over H x W as L planes of the concat
+ *                   buffer [B, Ctot, H, W] (encoder), and the backward of AdaptiveAvgPool2d(1) (scale = 1 / HW)
+ *   wm_plane_sum    v[b][l] = scale * sum of plane (b, c0 + l): AdaptiveAvgPool2d(1) (discriminator) and the message
+ *                   gradient
+ *   wm_bce_logits_fwd_bwd  nn.BCEWithLogitsLoss against a constant target (cover = 1, encoded = 0): *loss += mean,
+ *                   dlogits = gscale * (sigmoid(x) - target) / n (each NULL or output)
+ *   wm_linear_small_*  the Linear(channels, 1) head on the pooled features [M, K] (N <= K outputs; wm_gemm does not take an
+ *                   inner dimension of 1): y = x w^T + b; bwd: dx (NULL or output), dw / db ACCUMULATE (NULL to skip)       */
+int wm_plane_fill(const float* v, float* dst, int32_t B, int32_t L, int32_t Ctot, int32_t c0, int32_t HW, float scale,
+                  void* stream);
+int wm_plane_sum(const float* src, float* v, int32_t B, int32_t L, int32_t Ctot, int32_t c0, int32_t HW, float scale,
+                 void* stream);
+int wm_bce_logits_fwd_bwd(const float* logits, int32_t n, float target, float* loss, float* dlogits, float gscale,
+                          void* stream);
+int wm_linear_small_fwd(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t N, int32_t K,
+                        void* stream);
+int wm_linear_small_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int32_t M, int32_t N,
+                        int32_t K, void* stream);
+
 /* ---- HiDDeN image-domain distortions on [B, C, H, W] fp32 tiles (hidden/noise_layers/).  The random
  * rectangles / ratios / masks are drawn by the caller as the reference draws them (numpy) and passed in.  backward != 0
  * selects the adjoint / gradient form of the same entry point.

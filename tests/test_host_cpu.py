@@ -220,3 +220,25 @@ def test_custom_ops_are_registered_for_the_gpu_only(wm):
         torch.ops.wm.istft255(torch.zeros(1, 2, 128, 128))
     with pytest.raises(NotImplementedError):
         wm.tv_loss(torch.zeros(1, 1, 8, 8))
+
+
+def test_hidden_checkpoint_round_trip_and_layout(wm, tmp_path):
+    """hidden/utils.py:78-108: the checkpoint of the HiDDeN wrapper holds encoder_decoder / discriminator and both optimizers
+    and restores them; the containers carry the oracle's state_dict keys (host-only: no kernel runs)."""
+    from types import SimpleNamespace
+    from oracle import hidden_nets as O
+    hn = wm.hidden_nets
+    cfg = SimpleNamespace(message_length=30, encoder_blocks=2, encoder_channels=8, decoder_blocks=2, decoder_channels=8,
+                          discriminator_blocks=2, discriminator_channels=8, decoder_loss=1.0, encoder_loss=0.7, adversarial_loss=1e-3)
+    a, b = hn.Hidden(cfg, "cpu"), hn.Hidden(cfg, "cpu")
+    assert list(a.encoder_decoder.state_dict().keys()) == list(O.EncoderDecoder(cfg).state_dict().keys())
+    assert list(a.discriminator.state_dict().keys()) == list(O.HiddenDiscriminator(8, 2, 1).state_dict().keys())
+    path = hn.save_checkpoint(a, "exp", 3, str(tmp_path))
+    assert path.endswith("exp--epoch-3.pyt")
+    ck = torch.load(path, weights_only=True)
+    assert ck["epoch"] == 3
+    hn.model_from_checkpoint(b, ck)
+    for (k, v), (_, w) in zip(a.encoder_decoder.state_dict().items(), b.encoder_decoder.state_dict().items()):
+        assert torch.equal(v, w), k
+    with pytest.raises(wm.WmKernelError):
+        a.encoder_decoder(torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 4, 4))       # CPU tensors are refused, no fallback
