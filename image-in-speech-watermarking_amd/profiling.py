@@ -124,8 +124,12 @@ class KernelTimer:
         rows = []
         for key, recs in self.records.items():
             t = sum(s.elapsed_time(e) for s, e, *_ in recs) * 1e-3
+            # roofline time of the family with the bound chosen PER LAUNCH (a family mixes shapes on both sides of the ridge)
+            mfma = key.startswith("gemm") or key.startswith("winattn")
+            peak = MFMA_PEAK_TFLOPS[1 if recs[0][4] else 0] * 1e12
+            bound_s = sum(max(r[2] / peak if mfma else 0.0, r[3] / (HBM_PEAK_GBS * 1e9)) for r in recs)
             rows.append(dict(kernel=key, launches=len(recs), total_s=t, avg_us=t / len(recs) * 1e6,
-                             flops=sum(r[2] for r in recs), bytes=sum(r[3] for r in recs), mode=recs[0][4]))
+                             flops=sum(r[2] for r in recs), bytes=sum(r[3] for r in recs), mode=recs[0][4], bound_s=bound_s))
         rows.sort(key=lambda r: -r["total_s"])
         return rows
 
@@ -140,7 +144,8 @@ def roofline_of(row):
     tf, gb = row["flops"] / row["total_s"] / 1e12, row["bytes"] / row["total_s"] / 1e9
     common = dict(kernel=k, launches=n, avg_launch_us=row["avg_us"], alg_flops_per_launch=row["flops"] / n,
                   alg_bytes_per_launch=row["bytes"] / n, achieved_TFLOPs=tf, achieved_GBs=gb,
-                  frac_of_mfma_peak=tf / peak_tf, frac_of_hbm_peak=gb / HBM_PEAK_GBS, traffic=None)
+                  frac_of_mfma_peak=tf / peak_tf, frac_of_hbm_peak=gb / HBM_PEAK_GBS, traffic=None,
+                  frac_bound_per_launch=row.get("bound_s", 0.0) / row["total_s"])
     if t_mfma > t_hbm:
         return dict(bound="mfma", achieved=tf, peak=peak_tf, unit="TFLOP/s", frac=tf / peak_tf, **common)
     return dict(bound="hbm", achieved=gb, peak=HBM_PEAK_GBS, unit="GB/s", frac=gb / HBM_PEAK_GBS, **common)
