@@ -182,8 +182,7 @@ __global__ __launch_bounds__(64) void attn_fwd_fast_kernel(const __bf16* __restr
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 4; ++it)
-      *reinterpret_cast<uint4*>(out + row[it] * (int64_t)g.C + col) =
-          *reinterpret_cast<const uint4*>(Qs + ((lane >> 2) + 16 * it) * LDK + 8 * (lane & 3));
+      stream_store(out + row[it] * (int64_t)g.C + col, *reinterpret_cast<const uint4*>(Qs + ((lane >> 2) + 16 * it) * LDK + 8 * (lane & 3)));
   }
 }
 
@@ -315,8 +314,8 @@ __global__ __launch_bounds__(64) void attn_bwd_fast_kernel(const __bf16* __restr
       for (int t = 0; t < 2; ++t) {
         const int rl = (lane >> 2) + 16 * t;
         __bf16* dst = dqkv + row[2 * kj + t] * ld + col;
-        *reinterpret_cast<uint4*>(dst + g.C) = *reinterpret_cast<const uint4*>(Xs + rl * LDK + 8 * (lane & 3));
-        *reinterpret_cast<uint4*>(dst + 2 * g.C) = *reinterpret_cast<const uint4*>(Xs + (32 + rl) * LDK + 8 * (lane & 3));
+        stream_store(dst + g.C, *reinterpret_cast<const uint4*>(Xs + rl * LDK + 8 * (lane & 3)));
+        stream_store(dst + 2 * g.C, *reinterpret_cast<const uint4*>(Xs + (32 + rl) * LDK + 8 * (lane & 3)));
       }
     }
     // dQ: [query][e] accumulators (lane = e) -> LDS -> 16-byte chunks
@@ -328,8 +327,7 @@ __global__ __launch_bounds__(64) void attn_bwd_fast_kernel(const __bf16* __restr
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 4; ++it)
-      *reinterpret_cast<uint4*>(dqkv + row[it] * ld + col) =
-          *reinterpret_cast<const uint4*>(Xs + ((lane >> 2) + 16 * it) * LDK + 8 * (lane & 3));
+      stream_store(dqkv + row[it] * ld + col, *reinterpret_cast<const uint4*>(Xs + ((lane >> 2) + 16 * it) * LDK + 8 * (lane & 3)));
   }
   // relative-position-bias gradient: registers -> LDS bins -> one global atomic per bin.  (LDS float atomics cost
   // ~0.3 us per instruction here, so the bins are filled with plain read-add-write rounds instead: for one

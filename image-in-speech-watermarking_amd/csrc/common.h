@@ -68,10 +68,30 @@ __device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
   bf16x4 t = {(__bf16)a, (__bf16)b, (__bf16)0.f, (__bf16)0.f};
   return reinterpret_cast<const uint2&>(t).x;
 }
+// Streaming stores (the `nt` bit): activations and gradients written by one kernel are read back by a later launch, long
+// after they left the caches (hundreds of MB per tensor at bench batches); marking the store non-temporal keeps the lines
+// from displacing the operands that ARE re-read (weights, halo rows) on their way to HBM.
+typedef __attribute__((ext_vector_type(2))) unsigned int nt_u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int nt_u32x4;
+typedef __attribute__((ext_vector_type(4))) float nt_f32x4;
+__device__ __forceinline__ void stream_store(float* p, float4 v) {
+  __builtin_nontemporal_store((nt_f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f32x4*>(p));
+}
+__device__ __forceinline__ void stream_store(__bf16* p, uint2 v) {
+  __builtin_nontemporal_store((nt_u32x2){v.x, v.y}, reinterpret_cast<nt_u32x2*>(p));
+}
+__device__ __forceinline__ void stream_store(__bf16* p, uint4 v) {
+  __builtin_nontemporal_store((nt_u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(p));
+}
+__device__ __forceinline__ void stream_store(__bf16* p, uint32_t v) { __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(p)); }
+__device__ __forceinline__ void stream_store(float* p, float2 v) {
+  typedef __attribute__((ext_vector_type(2))) float nt_f32x2;
+  __builtin_nontemporal_store((nt_f32x2){v.x, v.y}, reinterpret_cast<nt_f32x2*>(p));
+}
 template <typename T> struct IO;
 template <> struct IO<float> {
   static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-  static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+  static __device__ __forceinline__ void st4(float* p, float4 v) { stream_store(p, v); }
   static __device__ __forceinline__ float ld1(const float* p) { return *p; }
   static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 };
@@ -81,7 +101,7 @@ template <> struct IO<__bf16> {
     return make_float4(bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y));
   }
   static __device__ __forceinline__ void st4(__bf16* p, float4 v) {
-    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    stream_store(p, make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)));
   }
   static __device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
   static __device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }

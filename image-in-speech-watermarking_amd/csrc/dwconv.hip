@@ -94,11 +94,13 @@ template <typename ST> struct Halo {
 template <typename ST> struct Pair;
 template <> struct Pair<__bf16> {
   typedef uint32_t raw;
+  static __device__ __forceinline__ void put(__bf16* p, f32x2 v) { stream_store(p, pack_bf2(v.x, v.y)); }
   static __device__ __forceinline__ f32x2 up(raw u) { f32x2 v = {bf_lo(u), bf_hi(u)}; return v; }
   static __device__ __forceinline__ raw down(f32x2 v) { return pack_bf2(v.x, v.y); }
 };
 template <> struct Pair<float> {
   typedef float2 raw;
+  static __device__ __forceinline__ void put(float* p, f32x2 v) { stream_store(p, make_float2(v.x, v.y)); }
   static __device__ __forceinline__ f32x2 up(raw u) { f32x2 v = {u.x, u.y}; return v; }
   static __device__ __forceinline__ raw down(f32x2 v) { return make_float2(v.x, v.y); }
 };
@@ -203,16 +205,15 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ST* __restrict__ 
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) o += wr[dy * 3 + dx] * col[(px + dx) % 3][dy];
     const int64_t off = row0 + (int64_t)px * Ch;
-    typedef typename Pair<ST>::raw raw;
-    if (h2) *reinterpret_cast<raw*>(h2 + off) = Pair<ST>::down(o);
+    if (h2) Pair<ST>::put(h2 + off, o);
     // second GELU and its derivative are materialised once here, from one shared exp(): evaluating them inside the
     // consumer GEMMs (A-operand staging of linear2 / dW2, epilogue of d_h2) repeated them per column tile and made
     // those launches VALU-bound
     if (a2 || g2) {
       f32x2 av, gv;
       gelu_pair<ST>(o, av, gv);
-      if (a2) *reinterpret_cast<raw*>(a2 + off) = Pair<ST>::down(av);
-      if (g2) *reinterpret_cast<raw*>(g2 + off) = Pair<ST>::down(gv);
+      if (a2) Pair<ST>::put(a2 + off, av);
+      if (g2) Pair<ST>::put(g2 + off, gv);
     }
   }
 }
@@ -279,7 +280,6 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restr
                                                                int Ch) {
   __shared__ __attribute__((aligned(16))) float ring[HP * RING * TC];
   __shared__ __attribute__((aligned(16))) float wl[10 * TC];
-  typedef typename Pair<ST>::raw raw;
   const int tid = threadIdx.x, nt = hw / TP;
   const int b = blockIdx.y / nt, ty = blockIdx.y % nt;     // channel chunks of one strip are neighbours in dispatch order
   const int cbase = blockIdx.x * TC;
@@ -322,12 +322,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restr
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) o += wr[dy * 3 + dx] * col[(px + dx) % 3][dy];
       const int64_t off = strip0 + (int64_t)(tx * TP + px) * Ch;
-      if (h2) *reinterpret_cast<raw*>(h2 + off) = Pair<ST>::down(o);
+      if (h2) Pair<ST>::put(h2 + off, o);
       if (a2 || g2) {
         f32x2 av, gv;
         gelu_pair<ST>(o, av, gv);
-        if (a2) *reinterpret_cast<raw*>(a2 + off) = Pair<ST>::down(av);
-        if (g2) *reinterpret_cast<raw*>(g2 + off) = Pair<ST>::down(gv);
+        if (a2) Pair<ST>::put(a2 + off, av);
+        if (g2) Pair<ST>::put(g2 + off, gv);
       }
     }
   }
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, sizeof(ST) == 2 ? 4 : 1) void dwconv_bwd_kerne
           aw[dy * 3 + dx] += a1 * g;
         }
       ab += col[(px + 1) % 3][1];
-      *reinterpret_cast<raw*>(dh1 + strip0 + (int64_t)(tx * TP + px) * Ch) = Pair<ST>::down(o * gp);
+      Pair<ST>::put(dh1 + strip0 + (int64_t)(tx * TP + px) * Ch, o * gp);
     }
   }
   // reduce the 20 per-thread sums over the 8 tile rows: the two rows of a wave by a lane exchange, the 4 waves via LDS

@@ -216,7 +216,7 @@ __device__ __forceinline__ void epi_interior(const float* cs, const WmGemm& g, i
       float4 v = *reinterpret_cast<const float4*>(cs + q * RPP * LDC);
       v.x = (v.x + bias4.x) * sc + re[q].x; v.y = (v.y + bias4.y) * sc + re[q].y;
       v.z = (v.z + bias4.z) * sc + re[q].z; v.w = (v.w + bias4.w) * sc + re[q].w;
-      *reinterpret_cast<float4*>(cf) = v;
+      stream_store(cf, v);
     }
   } else {
     __bf16* ch = static_cast<__bf16*>(g.C) + row0 * g.ldc + n;
@@ -225,7 +225,7 @@ __device__ __forceinline__ void epi_interior(const float* cs, const WmGemm& g, i
       float4 v = *reinterpret_cast<const float4*>(cs + q * RPP * LDC);
       if constexpr (EPI == 0) { v.x = (v.x + bias4.x) * sc; v.y = (v.y + bias4.y) * sc; v.z = (v.z + bias4.z) * sc; v.w = (v.w + bias4.w) * sc; }
       else { v.x *= sc * bf_lo(ga[q].x); v.y *= sc * bf_hi(ga[q].x); v.z *= sc * bf_lo(ga[q].y); v.w *= sc * bf_hi(ga[q].y); }
-      *reinterpret_cast<uint2*>(ch) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+      stream_store(ch, make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)));
     }
   }
 }

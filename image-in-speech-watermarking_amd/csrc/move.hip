@@ -48,7 +48,7 @@ __global__ void col2im_kernel(const IT* __restrict__ dcols, float* __restrict__ 
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
     }
-    *reinterpret_cast<float4*>(dx + pix * C + 4 * c4) = acc;
+    stream_store(dx + pix * C + 4 * c4, acc);
   }
 }
 
@@ -69,7 +69,7 @@ __global__ void shuffle_kernel(const IT* __restrict__ y4, const float* __restric
       v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
     }
     const int64_t row = ((int64_t)b * 2 * hw + 2 * i + (t >> 1)) * 2 * hw + 2 * j + (t & 1);
-    *reinterpret_cast<float4*>(dst + row * ldd + c0 + 4 * o4) = v;
+    stream_store(dst + row * ldd + c0 + 4 * o4, v);
   }
 }
 
@@ -101,7 +101,7 @@ __global__ void copy_cols_kernel(const float* __restrict__ src, int64_t lds, int
       const float4 o = *reinterpret_cast<const float4*>(d);
       v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
     }
-    *reinterpret_cast<float4*>(d) = v;
+    stream_store(d, v);
   }
 }
 

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const DT* __restrict__ dy, 
       o.z = rs * (g[q].z - s1 - xh[q].z * s2);
       o.w = rs * (g[q].w - s1 - xh[q].w * s2);
       if (dres) { o.x += dr[q].x; o.y += dr[q].y; o.z += dr[q].z; o.w += dr[q].w; }
-      *reinterpret_cast<float4*>(dx + row * C + c) = o;
+      stream_store(dx + row * C + c, o);
       // the next GEMMs (dX, dW) round this gradient to bf16 while staging it anyway: a bf16 copy written here halves
       // what they read and lets them run as bf16 x bf16 instances (identical numbers)
       if (dxh) IO<__bf16>::st4(dxh + row * C + c, o);
