@@ -273,7 +273,9 @@ __device__ __forceinline__ void cols_to_ring(float* ring, const u32x4 (&c)[NLD],
   }
 }
 
-template <typename ST>
+// TRAIN: the outputs of the train step (a2 and g2, no h2) are known at compile time: the per-pixel null checks of the
+// general form cost four scalar branches per pixel and keep the two GELU polynomials in separate blocks
+template <typename ST, bool TRAIN>
 __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restrict__ h1, const float* __restrict__ w,
                                                                const float* __restrict__ bias, ST* __restrict__ h2,
                                                                ST* __restrict__ a2, ST* __restrict__ g2, int B, int hw,
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restr
     __syncthreads();
     if (tx + 1 < nt) cols_load<ST, TP>(creg, h1, b, ty, (tx + 1) * TP + 1, hw, Ch, cbase, tid);
     const int s0 = tx * TP;                                   // ring slot of halo column lx: (s0 + lx) & 15
+    const int64_t tile0 = strip0 + (int64_t)tx * TP * Ch;
     auto at = [&](int dy, int x) {
       return *reinterpret_cast<const f32x2*>(ring + ((py + dy) * RING + ((s0 + x) & (RING - 1))) * TC + 2 * c2);
     };
@@ -321,13 +324,20 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restr
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) o += wr[dy * 3 + dx] * col[(px + dx) % 3][dy];
-      const int64_t off = strip0 + (int64_t)(tx * TP + px) * Ch;
-      if (h2) Pair<ST>::put(h2 + off, o);
-      if (a2 || g2) {
+      const int64_t off = tile0 + px * Ch;                  // 32-bit multiply-add on top of the tile's 64-bit offset
+      if (TRAIN) {
         f32x2 av, gv;
         gelu_pair<ST>(o, av, gv);
-        if (a2) Pair<ST>::put(a2 + off, av);
-        if (g2) Pair<ST>::put(g2 + off, gv);
+        Pair<ST>::put(a2 + off, av);
+        Pair<ST>::put(g2 + off, gv);
+      } else {
+        if (h2) Pair<ST>::put(h2 + off, o);
+        if (a2 || g2) {
+          f32x2 av, gv;
+          gelu_pair<ST>(o, av, gv);
+          if (a2) Pair<ST>::put(a2 + off, av);
+          if (g2) Pair<ST>::put(g2 + off, gv);
+        }
       }
     }
   }
@@ -375,6 +385,7 @@ __global__ __launch_bounds__(256, sizeof(ST) == 2 ? 4 : 1) void dwconv_bwd_kerne
     __syncthreads();
     const int txn = tx + 1 < nt ? tx + 1 : tx;               // next tile's loads fly during this tile's arithmetic
     halo_load<ST>(hreg, dh2, b, ty, txn, hw, Ch, cbase, tid);
+    const int64_t tile0 = strip0 + (int64_t)tx * TP * Ch, next0 = strip0 + (int64_t)txn * TP * Ch;
     f32x2 col[3][3];                                          // col[x % 3][row]: dh2 at halo row py + row, halo column x
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(256, sizeof(ST) == 2 ? 4 : 1) void dwconv_bwd_kerne
         col[(px + 2) % 3][rr] = Pair<ST>::up(*reinterpret_cast<const raw*>(tg + ((py + rr) * HP + px + 2) * TC + 2 * c2));
       f32x2 a1, gp;
       gelu_pair<ST>(Pair<ST>::up(hv[px]), a1, gp);
-      hv[px] = *reinterpret_cast<const raw*>(h1 + strip0 + (int64_t)(txn * TP + px) * Ch);
+      hv[px] = *reinterpret_cast<const raw*>(h1 + next0 + px * Ch);
       f32x2 o = {0.f, 0.f};
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(256, sizeof(ST) == 2 ? 4 : 1) void dwconv_bwd_kerne
           aw[dy * 3 + dx] += a1 * g;
         }
       ab += col[(px + 1) % 3][1];
-      Pair<ST>::put(dh1 + strip0 + (int64_t)(tx * TP + px) * Ch, o * gp);
+      Pair<ST>::put(dh1 + tile0 + px * Ch, o * gp);
     }
   }
   // reduce the 20 per-thread sums over the 8 tile rows: the two rows of a wave by a lane exchange, the 4 waves via LDS
@@ -460,11 +471,15 @@ extern "C" int wm_dwconv_fwd(const void* h1, const float* w, const float* b, voi
   const int nt = hw / TP;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (nt >= 2) {                                              // strips of two tiles and more: the ring saves up to a fifth of the first GELUs
-    if (io_bf16)
-      hipLaunchKernelGGL(dwconv_fwd_strip_kernel<__bf16>, dim3(Ch / TC, B * nt), dim3(256), 0, st,
+    const bool train = !h2 && a2 && g2;
+    if (io_bf16 && train)
+      hipLaunchKernelGGL((dwconv_fwd_strip_kernel<__bf16, true>), dim3(Ch / TC, B * nt), dim3(256), 0, st,
+                         static_cast<const __bf16*>(h1), w, b, static_cast<__bf16*>(h2), static_cast<__bf16*>(a2), static_cast<__bf16*>(g2), B, hw, Ch);
+    else if (io_bf16)
+      hipLaunchKernelGGL((dwconv_fwd_strip_kernel<__bf16, false>), dim3(Ch / TC, B * nt), dim3(256), 0, st,
                          static_cast<const __bf16*>(h1), w, b, static_cast<__bf16*>(h2), static_cast<__bf16*>(a2), static_cast<__bf16*>(g2), B, hw, Ch);
     else
-      hipLaunchKernelGGL(dwconv_fwd_strip_kernel<float>, dim3(Ch / TC, B * nt), dim3(256), 0, st,
+      hipLaunchKernelGGL((dwconv_fwd_strip_kernel<float, false>), dim3(Ch / TC, B * nt), dim3(256), 0, st,
                          static_cast<const float*>(h1), w, b, static_cast<float*>(h2), static_cast<float*>(a2), static_cast<float*>(g2), B, hw, Ch);
     WM_CHECK_LAUNCH();
     return WM_OK;
