@@ -38,14 +38,17 @@ __device__ __forceinline__ int64_t out_off(const WmConv& c, int b, int co, int y
   return c.out_nhwc ? (((int64_t)b * c.OH + y) * c.OW + x) * c.Cout + co
                     : (((int64_t)b * c.Cout + co) * c.OH + y) * c.OW + x;
 }
-__device__ __forceinline__ void out_decode(const WmConv& c, int64_t idx, int& b, int& co, int& y, int& x) {
+// IT = int when the tensor has fewer than 2^31 elements: 64-bit div / mod costs ~100 instructions each, four per output
+template <typename IT>
+__device__ __forceinline__ void out_decode(const WmConv& c, IT idx, int& b, int& co, int& y, int& x) {
   if (c.out_nhwc) {
     co = (int)(idx % c.Cout); idx /= c.Cout; x = (int)(idx % c.OW); idx /= c.OW; y = (int)(idx % c.OH); b = (int)(idx / c.OH);
   } else {
     x = (int)(idx % c.OW); idx /= c.OW; y = (int)(idx % c.OH); idx /= c.OH; co = (int)(idx % c.Cout); b = (int)(idx / c.Cout);
   }
 }
-__device__ __forceinline__ void in_decode(const WmConv& c, int64_t idx, int& b, int& ci, int& y, int& x) {
+template <typename IT>
+__device__ __forceinline__ void in_decode(const WmConv& c, IT idx, int& b, int& ci, int& y, int& x) {
   if (c.in_nhwc) {
     ci = (int)(idx % c.Cin); idx /= c.Cin; x = (int)(idx % c.W); idx /= c.W; y = (int)(idx % c.H); b = (int)(idx / c.H);
   } else {
@@ -53,12 +56,13 @@ __device__ __forceinline__ void in_decode(const WmConv& c, int64_t idx, int& b, 
   }
 }
 
+template <typename IT>
 __global__ void conv_fwd_kernel(const WmConv c, const float* __restrict__ x, const float* __restrict__ w,
-                                const float* __restrict__ bias, float* __restrict__ y, int64_t total) {
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
+                                const float* __restrict__ bias, float* __restrict__ y, int64_t total_) {
+  const IT total = (IT)total_;
+  for (IT idx = (IT)blockIdx.x * (IT)blockDim.x + (IT)threadIdx.x; idx < total; idx += (IT)gridDim.x * (IT)blockDim.x) {
     int b, co, oy, ox;
-    out_decode(c, idx, b, co, oy, ox);
+    out_decode<IT>(c, idx, b, co, oy, ox);
     float acc = bias ? bias[co] : 0.f;
     if (!c.transposed && c.in_nhwc && (c.Cin & 3) == 0) {
       // channel-contiguous input (OutputProj): 16-B loads along Cin; the weight index is wave-uniform for NCHW output
@@ -98,12 +102,13 @@ __global__ void conv_fwd_kernel(const WmConv c, const float* __restrict__ x, con
   }
 }
 
+template <typename IT>
 __global__ void conv_dx_kernel(const WmConv c, const float* __restrict__ w, const float* __restrict__ y,
-                               const float* __restrict__ dy, float* __restrict__ dx, int accumulate, int64_t total) {
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
+                               const float* __restrict__ dy, float* __restrict__ dx, int accumulate, int64_t total_) {
+  const IT total = (IT)total_;
+  for (IT idx = (IT)blockIdx.x * (IT)blockDim.x + (IT)threadIdx.x; idx < total; idx += (IT)gridDim.x * (IT)blockDim.x) {
     int b, ci, iy, ix;
-    in_decode(c, idx, b, ci, iy, ix);
+    in_decode<IT>(c, idx, b, ci, iy, ix);
     float acc = 0.f;
     if (!c.transposed && c.out_nhwc && (c.Cout & 3) == 0 && c.SH == 1 && c.SW == 1) {
       // channel-contiguous output gradient (InputProj): 16-B loads of dy and y along Cout
@@ -156,13 +161,15 @@ __global__ void conv_dx_kernel(const WmConv c, const float* __restrict__ w, cons
   }
 }
 
-// one workgroup per weight element (+ Cout extra workgroups for the bias)
+// workgroup (x: weight element, + Cout extra for the bias; y: slice of the batch): one atomic per workgroup.  The batch is
+// sliced because one workgroup per weight walked B * OH * OW positions alone (217 us per launch at B = 192).
 __global__ __launch_bounds__(256) void conv_dw_kernel(const WmConv c, const float* __restrict__ x,
                                                       const float* __restrict__ y, const float* __restrict__ dy,
-                                                      float* __restrict__ dw, float* __restrict__ db) {
+                                                      float* __restrict__ dw, float* __restrict__ db, int bper) {
   __shared__ float red[4];
   const int nW = c.Cout * c.Cin * c.KH * c.KW;
   const int e = blockIdx.x;
+  const int b0 = blockIdx.y * bper, b1 = min(c.B, b0 + bper);
   float acc = 0.f;
   if (e < nW) {
     int t = e;
@@ -171,27 +178,27 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const WmConv c, const floa
     int co, ci;
     if (!c.transposed) { ci = t % c.Cin; co = t / c.Cin; } else { co = t % c.Cout; ci = t / c.Cout; }
     if (!c.transposed) {
-      const int64_t n = (int64_t)c.B * c.OH * c.OW;
-      for (int64_t p = threadIdx.x; p < n; p += 256) {
-        const int ox = (int)(p % c.OW), oy = (int)((p / c.OW) % c.OH), b = (int)(p / ((int64_t)c.OW * c.OH));
+      const int n = (b1 - b0) * c.OH * c.OW;
+      for (int p = threadIdx.x; p < n; p += 256) {
+        const int ox = p % c.OW, oy = (p / c.OW) % c.OH, b = b0 + p / (c.OW * c.OH);
         const int iy = oy * c.SH - c.PH + ky, ix = ox * c.SW - c.PW + kx;
         if (iy < 0 || iy >= c.H || ix < 0 || ix >= c.W) continue;
         const int64_t o = out_off(c, b, co, oy, ox);
         acc += dy[o] * act_grad_from_out(y[o], c.act) * x[in_off(c, b, ci, iy, ix)];
       }
     } else {
-      const int64_t n = (int64_t)c.B * c.H * c.W;
-      for (int64_t p = threadIdx.x; p < n; p += 256) {
-        const int ix = (int)(p % c.W), iy = (int)((p / c.W) % c.H), b = (int)(p / ((int64_t)c.W * c.H));
+      const int n = (b1 - b0) * c.H * c.W;
+      for (int p = threadIdx.x; p < n; p += 256) {
+        const int ix = p % c.W, iy = (p / c.W) % c.H, b = b0 + p / (c.W * c.H);
         const int64_t o = out_off(c, b, co, iy * c.SH + ky, ix * c.SW + kx);
         acc += dy[o] * act_grad_from_out(y[o], c.act) * x[in_off(c, b, ci, iy, ix)];
       }
     }
   } else {
     const int co = e - nW;
-    const int64_t n = (int64_t)c.B * c.OH * c.OW;
-    for (int64_t p = threadIdx.x; p < n; p += 256) {
-      const int ox = (int)(p % c.OW), oy = (int)((p / c.OW) % c.OH), b = (int)(p / ((int64_t)c.OW * c.OH));
+    const int n = (b1 - b0) * c.OH * c.OW;
+    for (int p = threadIdx.x; p < n; p += 256) {
+      const int ox = p % c.OW, oy = (p / c.OW) % c.OH, b = b0 + p / (c.OW * c.OH);
       const int64_t o = out_off(c, b, co, oy, ox);
       acc += dy[o] * act_grad_from_out(y[o], c.act);
     }
@@ -332,8 +339,10 @@ extern "C" int wm_conv_fwd(const WmConv* c, const float* x, const float* w, cons
   const int edge = wm_conv_edge_fwd(*c, x, w, b, y, static_cast<hipStream_t>(stream));
   if (edge >= 0) return edge;
   const int64_t total = (int64_t)c->B * c->Cout * c->OH * c->OW;
-  hipLaunchKernelGGL(conv_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), *c, x, w,
-                     b, y, total);
+  if (total + 8192 * 256 < (int64_t)1 << 31)
+    hipLaunchKernelGGL(conv_fwd_kernel<int>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), *c, x, w, b, y, total);
+  else
+    hipLaunchKernelGGL(conv_fwd_kernel<int64_t>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), *c, x, w, b, y, total);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
@@ -347,7 +356,10 @@ extern "C" int wm_conv_bwd(const WmConv* c, const float* x, const float* w, cons
     if (edge > 0) return edge;
     if (edge < 0) {
       const int64_t total = (int64_t)c->B * c->Cin * c->H * c->W;
-      hipLaunchKernelGGL(conv_dx_kernel, dim3(grid_for(total)), dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate, total);
+      if (total + 8192 * 256 < (int64_t)1 << 31)
+        hipLaunchKernelGGL(conv_dx_kernel<int>, dim3(grid_for(total)), dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate, total);
+      else
+        hipLaunchKernelGGL(conv_dx_kernel<int64_t>, dim3(grid_for(total)), dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate, total);
       WM_CHECK_LAUNCH();
     }
   }
@@ -365,8 +377,13 @@ extern "C" int wm_conv_bwd(const WmConv* c, const float* x, const float* w, cons
     hipLaunchKernelGGL(conv3x3_dw_kernel, dim3((ntiles + tpb - 1) / tpb), dim3(256), smem, st, *c, x, y, dy, dw, db, tpb);
     WM_CHECK_LAUNCH();
   } else if (dw) {
-    const int nW = c->Cout * c->Cin * c->KH * c->KW;
-    hipLaunchKernelGGL(conv_dw_kernel, dim3(nW + (db ? c->Cout : 0)), dim3(256), 0, st, *c, x, y, dy, dw, db);
+    const int nW = c->Cout * c->Cin * c->KH * c->KW, nx = nW + (db ? c->Cout : 0);
+    // batch slices: about 4096 positions per workgroup, at most ~16 k workgroups, a slice never larger than 2^31 / 256 positions
+    const int64_t plane = (int64_t)(c->transposed ? c->H * c->W : c->OH * c->OW);
+    int bper = (int)(4096 / plane < 1 ? 1 : 4096 / plane);
+    while ((int64_t)nx * ((c->B + bper - 1) / bper) > 16384 && bper < c->B) bper *= 2;
+    if (plane * bper > (1 << 23)) return WM_EINVAL;
+    hipLaunchKernelGGL(conv_dw_kernel, dim3(nx, (c->B + bper - 1) / bper), dim3(256), 0, st, *c, x, y, dy, dw, db, bper);
     WM_CHECK_LAUNCH();
   }
   return WM_OK;
