@@ -99,13 +99,18 @@ __device__ __forceinline__ void mma3(f32x16& acc, const bf16x8& th, const bf16x8
 // frames [28 j - 4, 28 j + 28) that reach them, so no sum crosses a workgroup (frames outside [0, 128) are zero).
 template <bool ADJ>
 __global__ __launch_bounds__(256) void synth_mfma_kernel(const float* __restrict__ spec, float* __restrict__ wave,
-                                                         const __bf16* __restrict__ tab) {
+                                                         const __bf16* __restrict__ tab, int B) {
   __shared__ __attribute__((aligned(16))) char smem[FT * LDF * 4 + (ADJ ? SLOTS * HOP * 4 : 0)];
   __bf16* Xs = reinterpret_cast<__bf16*>(smem);               // [re|im][hi|lo][128 k][32 f] bf16 = 32 KB
   float* Fs = reinterpret_cast<float*>(smem);                 // [32 f][257] floats, after the products (aliases Xs)
   float* Ob = reinterpret_cast<float*>(smem + FT * LDF * 4);  // ADJ: this workgroup's padded-domain sums
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.y;
-  const int s0 = SLOTS * blockIdx.x, tf0 = s0 - 4;            // first slot / first frame (a multiple of 4, may be -4)
+  // Blocks are dealt round-robin to the 8 XCDs.  The 32-frame windows of a tile's five workgroups start at frame 28 j - 4:
+  // their 128-byte row segments straddle two cache lines each, and on five different L2s every line was fetched from
+  // HBM twice (PMC: 2.04 x the spectrum).  Linear id -> (tile, group) so that the groups of one tile share an XCD.
+  const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3, grp = sq % SYN_GROUPS, b = (sq / SYN_GROUPS) * 8 + xcd;
+  if (b >= B) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int s0 = SLOTS * grp, tf0 = s0 - 4;                   // first slot / first frame (a multiple of 4, may be -4)
   const float* src = spec + (int64_t)b * 2 * NBIN * NFRAME;
   // stage the 256 (plane, bin) rows x 32 frames: 8 float4 loads per thread, all issued before the first use
   float4 v[8];
@@ -292,15 +297,15 @@ extern "C" int wm_stft255_tables(void* tables, void* stream) {
 
 extern "C" int wm_istft255_fwd(const float* spec, float* wave, const void* tables, int32_t B, void* stream) {
   if (!spec || !wave || !tables || B <= 0 || !aligned16(spec) || !aligned16(tables)) return WM_EINVAL;
-  hipLaunchKernelGGL(synth_mfma_kernel<false>, dim3(SYN_GROUPS, B), dim3(256), 0, static_cast<hipStream_t>(stream), spec, wave,
-                     static_cast<const __bf16*>(tables));
+  hipLaunchKernelGGL(synth_mfma_kernel<false>, dim3(8 * ((B + 7) / 8) * SYN_GROUPS), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     spec, wave, static_cast<const __bf16*>(tables), B);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
 extern "C" int wm_stft255_bwd(const float* dspec, float* dwave, const void* tables, int32_t B, void* stream) {
   if (!dspec || !dwave || !tables || B <= 0 || !aligned16(dspec) || !aligned16(tables)) return WM_EINVAL;
-  hipLaunchKernelGGL(synth_mfma_kernel<true>, dim3(SYN_GROUPS, B), dim3(256), 0, static_cast<hipStream_t>(stream), dspec, dwave,
-                     static_cast<const __bf16*>(tables));
+  hipLaunchKernelGGL(synth_mfma_kernel<true>, dim3(8 * ((B + 7) / 8) * SYN_GROUPS), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dspec, dwave, static_cast<const __bf16*>(tables), B);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
