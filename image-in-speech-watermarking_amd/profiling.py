@@ -35,7 +35,7 @@ def _attn_cost(B, hw, C, products):
 COST = {
     "gemm": lambda *a, **k: _gemm_cost(a + (k,)),
     "winattn_fwd": lambda qkv, t, o, B, hw, C, sh, mode, lse=None: (_attn_cost(B, hw, C, 2), qkv.element_size() * B * hw * hw * 4.0 * C),
-    "winattn_bwd": lambda qkv, t, do, dq, dt, B, hw, C, sh, mode, out=None, lse=None, scratch=None, defer=None: (_attn_cost(B, hw, C, 6), qkv.element_size() * B * hw * hw * 7.0 * C),
+    "winattn_bwd": lambda qkv, t, do, dq, dt, B, hw, C, sh, mode, out=None, lse=None, scratch=None, defer=None: (_attn_cost(B, hw, C, 6), qkv.element_size() * B * hw * hw * 8.0 * C),   # q|k|v, dO, O read; dq|dk|dv written
     "dwconv_fwd": lambda h1, w, b, h2, B, hw, Ch, a2=None, g2=None: (18.0 * B * hw * hw * Ch, (1.0 + sum(t is not None for t in (h2, a2, g2))) * h1.element_size() * B * hw * hw * Ch),
     "dwconv_bwd": lambda h1, d, w, dh, dw, db, B, hw, Ch, scratch=None, defer=None: (54.0 * B * hw * hw * Ch, 3.0 * h1.element_size() * B * hw * hw * Ch),
     "layernorm_fwd": lambda x, g, b, m, y, *a: (8.0 * x.numel(), (4.0 + y.element_size()) * x.numel()),
