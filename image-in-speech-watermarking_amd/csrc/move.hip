@@ -7,33 +7,47 @@
 
 namespace {
 
-template <typename OT>
+// IX: index type of the flat loops below (int when the element count fits: 64-bit div / mod costs ~100 instructions each and
+// these kernels decode four to five of them per 16 bytes moved).  V: channels per thread (8 for bf16 columns: one 16-byte store).
+template <typename OT, typename IX, int V>
 __global__ void im2col_kernel(const float* __restrict__ x, OT* __restrict__ cols, int B, int hw, int C,
-                              int64_t total) {
-  const int c4n = C / 4, oh = hw / 2;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(idx % c4n);
-    const int tap = (int)((idx / c4n) % 16);
-    const int64_t m = idx / ((int64_t)c4n * 16);
-    const int j = (int)(m % oh), i = (int)((m / oh) % oh), b = (int)(m / ((int64_t)oh * oh));
+                              int64_t total_) {
+  const IX total = (IX)total_;
+  const int cvn = C / V, oh = hw / 2;
+  // Every input pixel belongs to four patches.  Blocks are dealt round-robin to the 8 XCDs, so neighbouring patches (neighbouring
+  // blocks) read the shared pixels through different L2s and HBM delivered x about twice (PMC 1.37 x the kernel's bytes):
+  // XCD k takes the k-th eighth of each grid-stride window instead (the grid is a multiple of 8).
+  const IX vb = (IX)(blockIdx.x & 7) * (IX)(gridDim.x >> 3) + (IX)(blockIdx.x >> 3);
+  for (IX idx = vb * (IX)blockDim.x + (IX)threadIdx.x; idx < total; idx += (IX)gridDim.x * (IX)blockDim.x) {
+    const int cv = (int)(idx % cvn);
+    const int tap = (int)((idx / cvn) % 16);
+    const IX m = idx / ((IX)cvn * 16);
+    const int j = (int)(m % oh), i = (int)((m / oh) % oh), b = (int)(m / ((IX)oh * oh));
     const int yy = 2 * i - 1 + (tap >> 2), xx = 2 * j - 1 + (tap & 3);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (yy >= 0 && yy < hw && xx >= 0 && xx < hw)
-      v = *reinterpret_cast<const float4*>(x + (((int64_t)b * hw + yy) * hw + xx) * C + 4 * c4);
-    IO<OT>::st4(cols + (m * 16 + tap) * C + 4 * c4, v);
+    const bool in = yy >= 0 && yy < hw && xx >= 0 && xx < hw;
+    const float* src = x + (((int64_t)b * hw + (in ? yy : 0)) * hw + (in ? xx : 0)) * C + V * cv;
+    OT* dst = cols + ((int64_t)m * 16 + tap) * C + V * cv;
+    float4 v0 = *reinterpret_cast<const float4*>(src);
+    if (!in) v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (V == 8) {
+      float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+      if (!in) v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      stream_store(dst, make_uint4(pack_bf2(v0.x, v0.y), pack_bf2(v0.z, v0.w), pack_bf2(v1.x, v1.y), pack_bf2(v1.z, v1.w)));
+    } else {
+      IO<OT>::st4(dst, v0);
+    }
   }
 }
 
-template <typename IT>
+template <typename IT, typename IX>
 __global__ void col2im_kernel(const IT* __restrict__ dcols, float* __restrict__ dx, int B, int hw, int C,
-                              int64_t total) {
+                              int64_t total_) {
+  const IX total = (IX)total_;
   const int c4n = C / 4, oh = hw / 2;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
+  for (IX idx = (IX)blockIdx.x * (IX)blockDim.x + (IX)threadIdx.x; idx < total; idx += (IX)gridDim.x * (IX)blockDim.x) {
     const int c4 = (int)(idx % c4n);
-    const int64_t pix = idx / c4n;
-    const int xx = (int)(pix % hw), yy = (int)((pix / hw) % hw), b = (int)(pix / ((int64_t)hw * hw));
+    const IX pix = idx / c4n;
+    const int xx = (int)(pix % hw), yy = (int)((pix / hw) % hw), b = (int)(pix / ((IX)hw * hw));
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -48,7 +62,7 @@ __global__ void col2im_kernel(const IT* __restrict__ dcols, float* __restrict__ 
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
     }
-    stream_store(dx + pix * C + 4 * c4, acc);
+    stream_store(dx + (int64_t)pix * C + 4 * c4, acc);
   }
 }
 
@@ -163,14 +177,19 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 extern "C" int wm_im2col_4x4s2(const float* x, void* cols, int32_t cols_bf16, int32_t B, int32_t hw, int32_t C,
                                void* stream) {
   if (!x || !cols || B <= 0 || hw < 2 || (hw & 1) || C < 4 || (C & 3)) return WM_EINVAL;
-  const int64_t total = (int64_t)B * (hw / 2) * (hw / 2) * 16 * (C / 4);
+  const bool v8 = cols_bf16 && !(C & 7);
+  const int64_t total = (int64_t)B * (hw / 2) * (hw / 2) * 16 * (C / (v8 ? 8 : 4));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (cols_bf16)
-    hipLaunchKernelGGL(im2col_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, x, static_cast<__bf16*>(cols), B, hw,
-                       C, total);
+  const unsigned grid = (grid_for(total) + 7) & ~7u;          // a multiple of 8: see the XCD mapping in the kernel
+  const bool small = total + (int64_t)grid * 256 < ((int64_t)1 << 31);
+  if (v8 && small)
+    hipLaunchKernelGGL((im2col_kernel<__bf16, int, 8>), dim3(grid), dim3(256), 0, st, x, static_cast<__bf16*>(cols), B, hw, C, total);
+  else if (v8)
+    hipLaunchKernelGGL((im2col_kernel<__bf16, int64_t, 8>), dim3(grid), dim3(256), 0, st, x, static_cast<__bf16*>(cols), B, hw, C, total);
+  else if (cols_bf16)
+    hipLaunchKernelGGL((im2col_kernel<__bf16, int64_t, 4>), dim3(grid), dim3(256), 0, st, x, static_cast<__bf16*>(cols), B, hw, C, total);
   else
-    hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, x, static_cast<float*>(cols), B, hw, C,
-                       total);
+    hipLaunchKernelGGL((im2col_kernel<float, int64_t, 4>), dim3(grid), dim3(256), 0, st, x, static_cast<float*>(cols), B, hw, C, total);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
@@ -179,11 +198,15 @@ extern "C" int wm_col2im_4x4s2(const void* dcols, int32_t dcols_bf16, float* dx,
   if (!dcols || !dx || B <= 0 || hw < 2 || (hw & 1) || C < 4 || (C & 3)) return WM_EINVAL;
   const int64_t total = (int64_t)B * hw * hw * (C / 4);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dcols_bf16)
-    hipLaunchKernelGGL(col2im_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const __bf16*>(dcols), dx,
+  const bool small = total + (int64_t)grid_for(total) * 256 < ((int64_t)1 << 31);
+  if (dcols_bf16 && small)
+    hipLaunchKernelGGL((col2im_kernel<__bf16, int>), dim3(grid_for(total)), dim3(256), 0, st, static_cast<const __bf16*>(dcols), dx,
                        B, hw, C, total);
+  else if (dcols_bf16)
+    hipLaunchKernelGGL((col2im_kernel<__bf16, int64_t>), dim3(grid_for(total)), dim3(256), 0, st, static_cast<const __bf16*>(dcols),
+                       dx, B, hw, C, total);
   else
-    hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const float*>(dcols), dx,
+    hipLaunchKernelGGL((col2im_kernel<float, int64_t>), dim3(grid_for(total)), dim3(256), 0, st, static_cast<const float*>(dcols), dx,
                        B, hw, C, total);
   WM_CHECK_LAUNCH();
   return WM_OK;
