@@ -161,6 +161,78 @@ __global__ void conv_dx_kernel(const WmConv c, const float* __restrict__ w, cons
   }
 }
 
+// 3x3 / stride 1 / pad 1 layers in NCHW with few channels (stft_layer 2 -> 4 -> 2 at 128 x 128, ConvAutoencoder 1 -> 16 and
+// 16 -> 4): a thread owns ONE pixel and all NO output channels (forward) or all input channels (input gradient), so the
+// nine taps of an input plane are read once per pixel instead of once per (pixel, channel), the weights are wave-uniform
+// scalar loads and no index is divided more than once per pixel.
+template <int NO>
+__global__ __launch_bounds__(256) void conv3x3_nchw_fwd_kernel(const WmConv c, const float* __restrict__ x,
+                                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ y) {
+  const int plane = c.H * c.W, p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (p >= plane) return;
+  const int oy = p / c.W, ox = p - oy * c.W;
+  float acc[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) acc[o] = bias ? bias[o] : 0.f;
+  const float* xb = x + (int64_t)b * c.Cin * plane;
+  for (int ci = 0; ci < c.Cin; ++ci) {
+    float t[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy + ky - 1, ix = ox + kx - 1;
+        const bool in = (unsigned)iy < (unsigned)c.H && (unsigned)ix < (unsigned)c.W;
+        const float v = xb[ci * plane + (in ? iy * c.W + ix : p)];
+        t[ky * 3 + kx] = in ? v : 0.f;
+      }
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[o] += t[k] * w[(o * c.Cin + ci) * 9 + k];
+  }
+  float* yb = y + (int64_t)b * NO * plane + p;
+#pragma unroll
+  for (int o = 0; o < NO; ++o) yb[o * plane] = act_f(acc[o], c.act);
+}
+
+// dx[b, ci, p] = sum over co, taps of (dy * act'(y))[b, co, p + 1 - k] * w[co][ci][k]; NI = Cin
+template <int NI>
+__global__ __launch_bounds__(256) void conv3x3_nchw_dx_kernel(const WmConv c, const float* __restrict__ w,
+                                                              const float* __restrict__ y, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, int accumulate) {
+  const int plane = c.H * c.W, p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (p >= plane) return;
+  const int iy = p / c.W, ix = p - iy * c.W;
+  float acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  const int64_t ob = (int64_t)b * c.Cout * plane;
+  for (int co = 0; co < c.Cout; ++co) {
+    float t[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int oy = iy + 1 - ky, ox = ix + 1 - kx;
+        const bool in = (unsigned)oy < (unsigned)c.H && (unsigned)ox < (unsigned)c.W;
+        const int64_t o = ob + co * plane + (in ? oy * c.W + ox : p);
+        const float g = dy[o] * act_grad_from_out(y[o], c.act);
+        t[ky * 3 + kx] = in ? g : 0.f;
+      }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[i] += t[k] * w[(co * NI + i) * 9 + k];
+  }
+  float* db_ = dx + (int64_t)b * NI * plane + p;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    if (accumulate) db_[i * plane] += acc[i]; else db_[i * plane] = acc[i];
+  }
+}
+
 // workgroup (x: weight element, + Cout extra for the bias; y: slice of the batch): one atomic per workgroup.  The batch is
 // sliced because one workgroup per weight walked B * OH * OW positions alone (217 us per launch at B = 192).
 __global__ __launch_bounds__(256) void conv_dw_kernel(const WmConv c, const float* __restrict__ x,
@@ -338,6 +410,20 @@ extern "C" int wm_conv_fwd(const WmConv* c, const float* x, const float* w, cons
   if (!conv_ok(c) || !x || !w || !y) return WM_EINVAL;
   const int edge = wm_conv_edge_fwd(*c, x, w, b, y, static_cast<hipStream_t>(stream));
   if (edge >= 0) return edge;
+  const bool nchw3 = !c->transposed && !c->in_nhwc && !c->out_nhwc && c->KH == 3 && c->KW == 3 && c->SH == 1 && c->SW == 1 &&
+                     c->PH == 1 && c->PW == 1 && c->B <= 65535 && c->Cin <= 64;
+  if (nchw3 && (c->Cout == 1 || c->Cout == 2 || c->Cout == 4 || c->Cout == 16)) {
+    const dim3 grid((c->H * c->W + 255) / 256, c->B);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (c->Cout) {
+      case 1: hipLaunchKernelGGL(conv3x3_nchw_fwd_kernel<1>, grid, dim3(256), 0, st, *c, x, w, b, y); break;
+      case 2: hipLaunchKernelGGL(conv3x3_nchw_fwd_kernel<2>, grid, dim3(256), 0, st, *c, x, w, b, y); break;
+      case 4: hipLaunchKernelGGL(conv3x3_nchw_fwd_kernel<4>, grid, dim3(256), 0, st, *c, x, w, b, y); break;
+      default: hipLaunchKernelGGL(conv3x3_nchw_fwd_kernel<16>, grid, dim3(256), 0, st, *c, x, w, b, y); break;
+    }
+    WM_CHECK_LAUNCH();
+    return WM_OK;
+  }
   const int64_t total = (int64_t)c->B * c->Cout * c->OH * c->OW;
   if (total + 8192 * 256 < (int64_t)1 << 31)
     hipLaunchKernelGGL(conv_fwd_kernel<int>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), *c, x, w, b, y, total);
@@ -354,7 +440,18 @@ extern "C" int wm_conv_bwd(const WmConv* c, const float* x, const float* w, cons
   if (dx) {
     const int edge = wm_conv_edge_dx(*c, w, y, dy, dx, dx_accumulate, st);
     if (edge > 0) return edge;
-    if (edge < 0) {
+    const bool nchw3 = !c->transposed && !c->in_nhwc && !c->out_nhwc && c->KH == 3 && c->KW == 3 && c->SH == 1 && c->SW == 1 &&
+                       c->PH == 1 && c->PW == 1 && c->B <= 65535 && c->Cout <= 64;
+    if (edge < 0 && nchw3 && (c->Cin == 1 || c->Cin == 2 || c->Cin == 4 || c->Cin == 16)) {
+      const dim3 grid((c->H * c->W + 255) / 256, c->B);
+      switch (c->Cin) {
+        case 1: hipLaunchKernelGGL(conv3x3_nchw_dx_kernel<1>, grid, dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate); break;
+        case 2: hipLaunchKernelGGL(conv3x3_nchw_dx_kernel<2>, grid, dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate); break;
+        case 4: hipLaunchKernelGGL(conv3x3_nchw_dx_kernel<4>, grid, dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate); break;
+        default: hipLaunchKernelGGL(conv3x3_nchw_dx_kernel<16>, grid, dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate); break;
+      }
+      WM_CHECK_LAUNCH();
+    } else if (edge < 0) {
       const int64_t total = (int64_t)c->B * c->Cin * c->H * c->W;
       if (total + 8192 * 256 < (int64_t)1 << 31)
         hipLaunchKernelGGL(conv_dx_kernel<int>, dim3(grid_for(total)), dim3(256), 0, st, *c, w, y, dy, dx, dx_accumulate, total);
