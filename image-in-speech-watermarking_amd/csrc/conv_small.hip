@@ -233,6 +233,59 @@ __global__ __launch_bounds__(256) void conv3x3_nchw_dx_kernel(const WmConv c, co
   }
 }
 
+// Weight / bias gradient of the same few-channel 3x3 NCHW layers: a thread walks pixels and keeps ALL NO x NI x 9 products and
+// the NO bias sums in registers (at most 160 + 16), the workgroup folds them with wave shuffles + LDS and issues one atomic per
+// weight.  (The tiled kernel below re-stages every 8 x 8 tile through LDS and spends two LDS reads per multiply-add.)
+template <int NO, int NI>
+__global__ __launch_bounds__(256) void conv3x3_nchw_dw_kernel(const WmConv c, const float* __restrict__ x,
+                                                              const float* __restrict__ y, const float* __restrict__ dy,
+                                                              float* __restrict__ dw, float* __restrict__ db, int per) {
+  constexpr int NA = NO * NI * 9 + NO;
+  __shared__ float red[4 * NA];
+  const int plane = c.H * c.W, tid = threadIdx.x;
+  float acc[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+  const int64_t n = (int64_t)c.B * plane;
+  const int64_t q0 = (int64_t)blockIdx.x * per, q1 = q0 + per < n ? q0 + per : n;
+  for (int64_t q = q0 + tid; q < q1; q += 256) {
+    const int b = (int)(q / plane), p = (int)(q - (int64_t)b * plane), py = p / c.W, px = p - py * c.W;
+    float g[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      const int64_t oo = ((int64_t)b * NO + o) * plane + p;
+      g[o] = dy[oo] * act_grad_from_out(y[oo], c.act);
+      acc[NO * NI * 9 + o] += g[o];
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float* xp = x + ((int64_t)b * NI + i) * plane;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int iy = py + ky - 1, ix = px + kx - 1;
+          const bool in = (unsigned)iy < (unsigned)c.H && (unsigned)ix < (unsigned)c.W;
+          const float v = xp[in ? iy * c.W + ix : p];
+          const float t = in ? v : 0.f;
+#pragma unroll
+          for (int o = 0; o < NO; ++o) acc[(o * NI + i) * 9 + ky * 3 + kx] += g[o] * t;
+        }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const float sum = wave_sum(acc[i]);
+    if ((tid & 63) == 0) red[(tid >> 6) * NA + i] = sum;
+  }
+  __syncthreads();
+  for (int i = tid; i < NA; i += 256) {
+    const float sum = (red[i] + red[NA + i]) + (red[2 * NA + i] + red[3 * NA + i]);
+    if (i < NO * NI * 9) atomicAdd(dw + i, sum);
+    else if (db) atomicAdd(db + (i - NO * NI * 9), sum);
+  }
+}
+
 // workgroup (x: weight element, + Cout extra for the bias; y: slice of the batch): one atomic per workgroup.  The batch is
 // sliced because one workgroup per weight walked B * OH * OW positions alone (217 us per launch at B = 192).
 __global__ __launch_bounds__(256) void conv_dw_kernel(const WmConv c, const float* __restrict__ x,
@@ -463,6 +516,21 @@ extern "C" int wm_conv_bwd(const WmConv* c, const float* x, const float* w, cons
   if (dw) {
     const int edge = wm_conv_edge_dw(*c, x, y, dy, dw, db, st);
     if (edge >= 0) return edge;
+  }
+  if (dw && !c->transposed && !c->in_nhwc && !c->out_nhwc && c->KH == 3 && c->KW == 3 && c->SH == 1 && c->SW == 1 && c->PH == 1 &&
+      c->PW == 1) {
+    const int64_t n = (int64_t)c->B * c->H * c->W;
+    int64_t per = (n + 511) / 512;                            // up to 512 workgroups (each ends in NA contended atomics), >= 1024 pixels each
+    if (per < 1024) per = 1024;
+    per = (per + 255) / 256 * 256;
+    const dim3 grid((unsigned)((n + per - 1) / per));
+#define WM_DW3(NO, NI) \
+    { hipLaunchKernelGGL((conv3x3_nchw_dw_kernel<NO, NI>), grid, dim3(256), 0, st, *c, x, y, dy, dw, db, (int)per); WM_CHECK_LAUNCH(); return WM_OK; }
+    if (c->Cout == 4 && c->Cin == 2) WM_DW3(4, 2)
+    if (c->Cout == 2 && c->Cin == 4) WM_DW3(2, 4)
+    if (c->Cout == 16 && c->Cin == 1) WM_DW3(16, 1)
+    if (c->Cout == 1 && c->Cin == 1) WM_DW3(1, 1)
+#undef WM_DW3
   }
   const bool tiled = dw && !c->transposed && c->KH == 3 && c->KW == 3 && c->SH == 1 && c->SW == 1 && c->PH == 1 &&
                      c->PW == 1 && (c->H % 8) == 0 && (c->W % 8) == 0 &&

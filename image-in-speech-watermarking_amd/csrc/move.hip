@@ -67,17 +67,17 @@ __global__ void col2im_kernel(const IT* __restrict__ dcols, float* __restrict__ 
 }
 
 // y4[m, t*Co + o] (+ bias[o]) -> dst[b, 2i+di, 2j+dj, c0+o]
-template <typename IT>
+template <typename IT, typename IX>
 __global__ void shuffle_kernel(const IT* __restrict__ y4, const float* __restrict__ bias, float* __restrict__ dst,
-                               int B, int hw, int Co, int64_t ldd, int c0, int64_t total) {
+                               int B, int hw, int Co, int64_t ldd, int c0, int64_t total_) {
+  const IX total = (IX)total_;
   const int o4n = Co / 4;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
+  for (IX idx = (IX)blockIdx.x * (IX)blockDim.x + (IX)threadIdx.x; idx < total; idx += (IX)gridDim.x * (IX)blockDim.x) {
     const int o4 = (int)(idx % o4n);
     const int t = (int)((idx / o4n) % 4);
-    const int64_t m = idx / ((int64_t)o4n * 4);
-    const int j = (int)(m % hw), i = (int)((m / hw) % hw), b = (int)(m / ((int64_t)hw * hw));
-    float4 v = IO<IT>::ld4(y4 + (m * 4 + t) * Co + 4 * o4);
+    const IX m = idx / ((IX)o4n * 4);
+    const int j = (int)(m % hw), i = (int)((m / hw) % hw), b = (int)(m / ((IX)hw * hw));
+    float4 v = IO<IT>::ld4(y4 + ((int64_t)m * 4 + t) * Co + 4 * o4);
     if (bias) {
       const float4 bb = *reinterpret_cast<const float4*>(bias + 4 * o4);
       v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
@@ -87,18 +87,18 @@ __global__ void shuffle_kernel(const IT* __restrict__ y4, const float* __restric
   }
 }
 
-template <typename OT>
+template <typename OT, typename IX>
 __global__ void unshuffle_kernel(const float* __restrict__ dsrc, OT* __restrict__ dy4, int B, int hw, int Co,
-                                 int64_t lds, int c0, int64_t total) {
+                                 int64_t lds, int c0, int64_t total_) {
+  const IX total = (IX)total_;
   const int o4n = Co / 4;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
+  for (IX idx = (IX)blockIdx.x * (IX)blockDim.x + (IX)threadIdx.x; idx < total; idx += (IX)gridDim.x * (IX)blockDim.x) {
     const int o4 = (int)(idx % o4n);
     const int t = (int)((idx / o4n) % 4);
-    const int64_t m = idx / ((int64_t)o4n * 4);
-    const int j = (int)(m % hw), i = (int)((m / hw) % hw), b = (int)(m / ((int64_t)hw * hw));
+    const IX m = idx / ((IX)o4n * 4);
+    const int j = (int)(m % hw), i = (int)((m / hw) % hw), b = (int)(m / ((IX)hw * hw));
     const int64_t row = ((int64_t)b * 2 * hw + 2 * i + (t >> 1)) * 2 * hw + 2 * j + (t & 1);
-    IO<OT>::st4(dy4 + (m * 4 + t) * Co + 4 * o4, *reinterpret_cast<const float4*>(dsrc + row * lds + c0 + 4 * o4));
+    IO<OT>::st4(dy4 + ((int64_t)m * 4 + t) * Co + 4 * o4, *reinterpret_cast<const float4*>(dsrc + row * lds + c0 + 4 * o4));
   }
 }
 
@@ -216,11 +216,15 @@ extern "C" int wm_pixel_shuffle2(const void* y4, int32_t y4_bf16, const float* b
   if (!y4 || !dst || B <= 0 || hw <= 0 || Co < 4 || (Co & 3) || (ldd & 3) || (c0 & 3) || !al16(dst)) return WM_EINVAL;
   const int64_t total = (int64_t)B * hw * hw * 4 * (Co / 4);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (y4_bf16)
-    hipLaunchKernelGGL(shuffle_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const __bf16*>(y4), bias,
+  const bool small = total + (int64_t)grid_for(total) * 256 < ((int64_t)1 << 31);
+  if (y4_bf16 && small)
+    hipLaunchKernelGGL((shuffle_kernel<__bf16, int>), dim3(grid_for(total)), dim3(256), 0, st, static_cast<const __bf16*>(y4), bias,
                        dst, B, hw, Co, ldd, c0, total);
+  else if (y4_bf16)
+    hipLaunchKernelGGL((shuffle_kernel<__bf16, int64_t>), dim3(grid_for(total)), dim3(256), 0, st, static_cast<const __bf16*>(y4),
+                       bias, dst, B, hw, Co, ldd, c0, total);
   else
-    hipLaunchKernelGGL(shuffle_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const float*>(y4), bias,
+    hipLaunchKernelGGL((shuffle_kernel<float, int64_t>), dim3(grid_for(total)), dim3(256), 0, st, static_cast<const float*>(y4), bias,
                        dst, B, hw, Co, ldd, c0, total);
   WM_CHECK_LAUNCH();
   return WM_OK;
@@ -231,11 +235,15 @@ extern "C" int wm_pixel_unshuffle2(const float* dsrc, void* dy4, int32_t dy4_bf1
     return WM_EINVAL;
   const int64_t total = (int64_t)B * hw * hw * 4 * (Co / 4);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dy4_bf16)
-    hipLaunchKernelGGL(unshuffle_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, dsrc, static_cast<__bf16*>(dy4), B,
+  const bool small = total + (int64_t)grid_for(total) * 256 < ((int64_t)1 << 31);
+  if (dy4_bf16 && small)
+    hipLaunchKernelGGL((unshuffle_kernel<__bf16, int>), dim3(grid_for(total)), dim3(256), 0, st, dsrc, static_cast<__bf16*>(dy4), B,
                        hw, Co, lds, c0, total);
+  else if (dy4_bf16)
+    hipLaunchKernelGGL((unshuffle_kernel<__bf16, int64_t>), dim3(grid_for(total)), dim3(256), 0, st, dsrc, static_cast<__bf16*>(dy4),
+                       B, hw, Co, lds, c0, total);
   else
-    hipLaunchKernelGGL(unshuffle_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, dsrc, static_cast<float*>(dy4), B,
+    hipLaunchKernelGGL((unshuffle_kernel<float, int64_t>), dim3(grid_for(total)), dim3(256), 0, st, dsrc, static_cast<float*>(dy4), B,
                        hw, Co, lds, c0, total);
   WM_CHECK_LAUNCH();
   return WM_OK;
