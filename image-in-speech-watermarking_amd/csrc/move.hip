@@ -119,16 +119,16 @@ __global__ void copy_cols_kernel(const float* __restrict__ src, int64_t lds, int
   }
 }
 
-template <typename OT>
+template <typename OT, typename IX>                          // IX = int when every offset fits (weight re-layouts: always)
 __global__ void strided3_kernel(const float* __restrict__ in, OT* __restrict__ out, int n0, int n1, int n2,
-                                int64_t si0, int64_t si1, int64_t si2, int64_t so0, int64_t so1, int64_t so2,
+                                int64_t si0_, int64_t si1_, int64_t si2_, int64_t so0_, int64_t so1_, int64_t so2_,
                                 int atomic) {
-  const int64_t total = (int64_t)n0 * n1 * n2;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int i2 = (int)(idx % n2), i1 = (int)((idx / n2) % n1), i0 = (int)(idx / ((int64_t)n1 * n2));
+  const IX si0 = (IX)si0_, si1 = (IX)si1_, si2 = (IX)si2_, so0 = (IX)so0_, so1 = (IX)so1_, so2 = (IX)so2_;
+  const IX total = (IX)n0 * n1 * n2;
+  for (IX idx = (IX)blockIdx.x * (IX)blockDim.x + (IX)threadIdx.x; idx < total; idx += (IX)gridDim.x * (IX)blockDim.x) {
+    const int i2 = (int)(idx % n2), i1 = (int)((idx / n2) % n1), i0 = (int)(idx / ((IX)n1 * n2));
     const float v = in[i0 * si0 + i1 * si1 + i2 * si2];
-    OT* d = out + i0 * so0 + i1 * so1 + i2 * so2;
+    OT* d = out + (i0 * so0 + i1 * so1 + i2 * so2);
     if constexpr (sizeof(OT) == 4) { if (atomic) atomicAdd(d, v); else *d = v; } else { *d = (OT)v; }
   }
 }
@@ -263,12 +263,25 @@ extern "C" int wm_strided3(const float* in, void* out, int32_t out_bf16, int32_t
                            int64_t si1, int64_t si2, int64_t so0, int64_t so1, int64_t so2, int32_t atomic, void* stream) {
   if (!in || !out || n0 <= 0 || n1 <= 0 || n2 <= 0 || (out_bf16 && atomic)) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (out_bf16)
-    hipLaunchKernelGGL(strided3_kernel<__bf16>, dim3(grid_for((int64_t)n0 * n1 * n2)), dim3(256), 0, st, in,
-                       static_cast<__bf16*>(out), n0, n1, n2, si0, si1, si2, so0, so1, so2, 0);
+  const int64_t total = (int64_t)n0 * n1 * n2, lim = (int64_t)1 << 30;
+  auto span = [&](int64_t a, int64_t b, int64_t c) {
+    return (n0 - 1) * (a < 0 ? -a : a) + (n1 - 1) * (b < 0 ? -b : b) + (n2 - 1) * (c < 0 ? -c : c);
+  };
+  const bool small = total < lim && span(si0, si1, si2) < lim && span(so0, so1, so2) < lim && si0 >= 0 && si1 >= 0 && si2 >= 0 &&
+                     so0 >= 0 && so1 >= 0 && so2 >= 0;
+  const dim3 grid(grid_for(total));
+  if (out_bf16 && small)
+    hipLaunchKernelGGL((strided3_kernel<__bf16, int>), grid, dim3(256), 0, st, in, static_cast<__bf16*>(out), n0, n1, n2, si0, si1,
+                       si2, so0, so1, so2, 0);
+  else if (out_bf16)
+    hipLaunchKernelGGL((strided3_kernel<__bf16, int64_t>), grid, dim3(256), 0, st, in, static_cast<__bf16*>(out), n0, n1, n2, si0, si1,
+                       si2, so0, so1, so2, 0);
+  else if (small)
+    hipLaunchKernelGGL((strided3_kernel<float, int>), grid, dim3(256), 0, st, in, static_cast<float*>(out), n0, n1, n2, si0, si1, si2,
+                       so0, so1, so2, atomic);
   else
-    hipLaunchKernelGGL(strided3_kernel<float>, dim3(grid_for((int64_t)n0 * n1 * n2)), dim3(256), 0, st, in,
-                       static_cast<float*>(out), n0, n1, n2, si0, si1, si2, so0, so1, so2, atomic);
+    hipLaunchKernelGGL((strided3_kernel<float, int64_t>), grid, dim3(256), 0, st, in, static_cast<float*>(out), n0, n1, n2, si0, si1,
+                       si2, so0, so1, so2, atomic);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
