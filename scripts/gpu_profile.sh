@@ -6,7 +6,7 @@
 set -o pipefail
 R=${1:-r02}; shift
 ARGS="$@"
-B=192; MODE=bf16; ATT=full
+B=256; MODE=bf16; ATT=full
 set -- $ARGS
 while [ $# -gt 0 ]; do case $1 in --batch) B=$2; shift;; --mode) MODE=$2; shift;; --attack) ATT=$2; shift;; esac; shift; done
 TAG=b${B}_${MODE}_${ATT}
