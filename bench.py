@@ -78,7 +78,10 @@ def launch_ranks(a):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # rank 0 prints ONE JSON line; libraries may add their own chatter to its stdout (gloo announces its peers in the one-GPU
+    # rehearsal): relay the JSON line alone, the rest goes to stderr
+    for line in out.decode().splitlines():
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 

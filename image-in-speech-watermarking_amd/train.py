@@ -180,6 +180,9 @@ class TrainStep:
             self._launch()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # the capture below allocates the whole step again from the graph's private pool: hand the warm-up pass's cached blocks
+        # (≈0.5 GB per tile at the end of the forward) back first instead of leaving it to the allocator's out-of-memory retry
+        torch.cuda.empty_cache()
 
     def _capture_segments(self):
         """Capture the launch sequence as graphs cut where backward has finished a gradient bucket.  Nothing executes
