@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256,
                     help="tiles per GPU.  The per-device batch is free (SURVEY 8: the reference script hard-codes 24, its CLI default "
-                         "is 4).  256 tiles use about 53 GB of the 288 GB: at B=24 a launch puts ~1.5 workgroups on each CU and the step is "
+                         "is 4).  256 tiles hold about 143 GB of the 288 GB at the end of the forward (0.56 GB per tile): at B=24 a launch puts ~1.5 workgroups on each CU and the step is "
                          "latency-bound; the rate rises 0.87 -> 1.32 -> 1.44 -> 1.48 -> 1.51 k audio-s/s over B = 24 / 96 / 192 / 256 / 384. "
                          "The line also reports the B=24 rate (reference_batch) measured in the same run.")
     ap.add_argument("--no-reference-batch", action="store_true", help="skip the extra B=24 measurement")
