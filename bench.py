@@ -293,38 +293,8 @@ def main():
 
     dt = timed(step, x, msg, a.steps, max(a.warmup, 2))           # >= 2: first call warms up + captures the graph
     losses = step.losses.cpu().tolist()
-    ref_batch = identity = None
-    if a.batch != 24 and not a.no_reference_batch and a.clip_seconds == 1:
-        # the same step at the batch the reference script hard-codes (audio_uformer_stft.py:50), timed the same way
-        step24 = wm.TrainStep(net, opt, 24, attack=attack, extract_from=extract_from, use_graph=not a.no_graph)
-        dt24 = timed(step24, x[:24], msg[:24], 10, 3)
-        ref_batch = {"tiles_per_gpu": 24, "value": world * 24 * TILE_SECONDS * 10 / dt24, "ms_per_step": dt24 / 10 * 1e3, "steps": 10}
-        del step24
-    if attacked and not a.no_identity_leg and a.clip_seconds == 1:
-        # BASELINE config 2 (Identity attack) at the same batch, as a secondary field
-        step_id = wm.TrainStep(net, opt, a.batch, attack=None, extract_from="y", use_graph=not a.no_graph)
-        dti = timed(step_id, x, msg, 10, 3)
-        identity = {"workload": workload_name(a, False), "value": world * a.batch * TILE_SECONDS * 10 / dti,
-                    "ms_per_step": dti / 10 * 1e3, "steps": 10}
-        del step_id
-
-    result = {
-        "metric": "audio-sec/s per train step (enc+attack+dec)", "value": world * a.batch * TILE_SECONDS * a.steps / dt,
-        "unit": "audio-sec/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
-        "config": {"workload": workload_name(a, attacked),
-                   "baseline_config": 5 if a.clip_seconds == 10 else (3 if attacked else 2),
-                   "tiles_per_gpu": a.batch, "global_tiles": world * a.batch, "audio_sec_per_tile": TILE_SECONDS,
-                   "parallelism": f"dp{world}", "graph": step.use_graph,
-                   "graph_segments": (4 if step.segmented else 1) if step.use_graph else 0, "params_M": 68.71},
-        "loss_terms": losses[:5],
-    }
-    if ref_batch is not None:
-        result["reference_batch"] = ref_batch
-    if identity is not None:
-        result["identity_attack"] = identity
-    if ber is not None:
-        result["ber"] = ber
+    used_graph, segmented = step.use_graph, step.segmented
+    allreduce = None
     if world > 1:
         # per-bucket gradient all-reduce time on the side stream (3 more steps; events on the communication stream)
         step.sync.timing = []
@@ -336,8 +306,46 @@ def main():
             per.setdefault(idx, []).append(s.elapsed_time(e))
         step.sync.timing = None
         mb = [b.numel() * 4 / 1e6 for b in net.grad_buckets()]
-        result["allreduce"] = [{"bucket": ("extractor", "decoder", "encoder")[i], "MB": round(mb[i], 1),
-                                "ms": round(statistics.median(per[i]), 3)} for i in sorted(per)]
+        allreduce = [{"bucket": ("extractor", "decoder", "encoder")[i], "MB": round(mb[i], 1),
+                      "ms": round(statistics.median(per[i]), 3)} for i in sorted(per)]
+    # the captured step holds 0.56 GB per tile; the legs below build their own steps at the same batch: give the memory back first
+    step.release()
+    ref_batch = identity = None
+    if a.batch != 24 and not a.no_reference_batch and a.clip_seconds == 1:
+        # the same step at the batch the reference script hard-codes (audio_uformer_stft.py:50), timed the same way
+        step24 = wm.TrainStep(net, opt, 24, attack=attack, extract_from=extract_from, use_graph=not a.no_graph)
+        dt24 = timed(step24, x[:24], msg[:24], 10, 3)
+        ref_batch = {"tiles_per_gpu": 24, "value": world * 24 * TILE_SECONDS * 10 / dt24, "ms_per_step": dt24 / 10 * 1e3, "steps": 10}
+        step24.release()
+        del step24
+    if attacked and not a.no_identity_leg and a.clip_seconds == 1:
+        # BASELINE config 2 (Identity attack) at the same batch, as a secondary field
+        step_id = wm.TrainStep(net, opt, a.batch, attack=None, extract_from="y", use_graph=not a.no_graph)
+        dti = timed(step_id, x, msg, 10, 3)
+        identity = {"workload": workload_name(a, False), "value": world * a.batch * TILE_SECONDS * 10 / dti,
+                    "ms_per_step": dti / 10 * 1e3, "steps": 10}
+        step_id.release()
+        del step_id
+
+    result = {
+        "metric": "audio-sec/s per train step (enc+attack+dec)", "value": world * a.batch * TILE_SECONDS * a.steps / dt,
+        "unit": "audio-sec/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
+        "config": {"workload": workload_name(a, attacked),
+                   "baseline_config": 5 if a.clip_seconds == 10 else (3 if attacked else 2),
+                   "tiles_per_gpu": a.batch, "global_tiles": world * a.batch, "audio_sec_per_tile": TILE_SECONDS,
+                   "parallelism": f"dp{world}", "graph": used_graph,
+                   "graph_segments": (4 if segmented else 1) if used_graph else 0, "params_M": 68.71},
+        "loss_terms": losses[:5],
+    }
+    if ref_batch is not None:
+        result["reference_batch"] = ref_batch
+    if identity is not None:
+        result["identity_attack"] = identity
+    if ber is not None:
+        result["ber"] = ber
+    if allreduce is not None:
+        result["allreduce"] = allreduce
     if rank == 0 and world == 1 and not a.no_kernel_timing:
         kernel_rooflines(a, wm, net, opt, attack, extract_from, x, msg, result)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -173,6 +173,18 @@ class TrainStep:
             return                                              # the capture pass itself does not execute: replay next
         self._graph.replay()
 
+    def release(self):
+        """Drop the captured graph(s) and their memory pool (0.56 GB per tile) and hand the allocator's cache back; the next
+        ``step`` captures again.  For callers that keep several TrainStep objects of bench-sized batches around."""
+        import gc
+        self._graph = None
+        self._segments = None
+        self.outputs = None
+        self._tape = None
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
     def _warm_up(self):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
