@@ -56,7 +56,7 @@ _SIGS = {
     "wm_layernorm_fwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f],
     "wm_layernorm_bwd_scratch_floats": [c_i32],
     "wm_reduce_jobs": [C.POINTER(WmReduceJob), c_i32, c_f],
-    "wm_layernorm_bwd": [c_f, c_i32] + [c_f] * 11 + [C.POINTER(WmReduceJob), c_i64, c_i32, c_i32, c_i32, c_f],
+    "wm_layernorm_bwd": [c_f, c_i32] + [c_f] * 11 + [C.POINTER(WmReduceJob), c_i64, c_i32, c_i32, c_i32, c_f, c_i32, c_f],
     "wm_winattn_fwd": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_winattn_bwd_scratch_floats": [],
     "wm_winattn_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.POINTER(WmReduceJob), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
@@ -70,6 +70,7 @@ _SIGS = {
     "wm_copy_cols": [c_f, c_i64, c_i32, c_f, c_i64, c_i32, c_i64, c_i32, c_i32, c_f],
     "wm_strided3": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_f],
     "wm_cast_bf16": [c_f, c_f, c_i64, c_f],
+    "wm_transpose_cast_jobs": [c_f, c_f, c_f, c_i32, c_i32, c_f],
     "wm_msg_expand_fwd": [c_f, c_f, c_i32, c_f],
     "wm_msg_expand_bwd": [c_f, c_f, c_i32, c_f],
     "wm_conv_fwd": [C.POINTER(WmConv), c_f, c_f, c_f, c_f, c_f],

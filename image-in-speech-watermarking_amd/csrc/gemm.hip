@@ -571,9 +571,13 @@ int dispatch(const WmGemm& g, int ksplit, hipStream_t st) {
 }  // namespace
 
 int wm_gemm_fast_bf16(const WmGemm& g, hipStream_t st);   // gemm_fast.hip: branch-free bf16 kernels, -1 = not applicable
+int wm_gemm_big_bf16(const WmGemm& g, hipStream_t st);    // gemm_big.hip: 256 x 256 tiles for the compute-side shapes, -1 = not applicable
+int wm_gemm_big_tn_bf16(const WmGemm& g, hipStream_t st); // ... its weight-gradient form
 
-extern "C" int wm_abi_version(void) { return 3; }
-extern "C" int64_t wm_gemm_scratch_floats(void) { return 384LL * 128 * 128 + 1024 * 1024; }
+extern "C" int wm_abi_version(void) { return 4; }
+// split-K slices of one weight-gradient launch: the 128 x 128 kernel writes up to ~384 tiles, the 256 x 256 kernel one tile
+// per CU (256 x 65536 floats = 67 MB)
+extern "C" int64_t wm_gemm_scratch_floats(void) { return 256LL * 256 * 256 + 1024 * 1024; }
 
 extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
   if (!gp) return WM_EINVAL;
@@ -593,7 +597,11 @@ extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (g.mode == 0) return dispatch<float, float, float, false, 32>(g, g.ksplit, st);
   if (g.mode == 1) {
-    const int rc = wm_gemm_fast_bf16(g, st);
+    int rc = wm_gemm_big_bf16(g, st);
+    if (rc >= 0) return rc;
+    rc = wm_gemm_big_tn_bf16(g, st);
+    if (rc >= 0) return rc;
+    rc = wm_gemm_fast_bf16(g, st);
     if (rc >= 0) return rc;
   }
   if (g.mode == 1) {

@@ -144,6 +144,36 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restri
     IO<__bf16>::st4(dst + 4 * i, *reinterpret_cast<const float4*>(src + 4 * i));
 }
 
+// Transposed bf16 copies of many [rows, cols] fp32 matrices of one arena in ONE launch (the dX GEMMs of the big-tile kernel
+// read their weights K-contiguous: gemm_big.hip).  job = {element offset of the matrix in both arenas, rows, cols, first
+// tile}; a workgroup moves one 64 x 64 tile through LDS (256-byte row reads, 128-byte row writes).
+__global__ __launch_bounds__(256) void transpose_cast_jobs_kernel(const float* __restrict__ src, __bf16* __restrict__ dst,
+                                                                  const int4* __restrict__ jobs, int njobs) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = njobs - 1;                                    // last job whose first tile is <= this block
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].w <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int4 jb = jobs[lo];
+  const int rows = jb.y, cols = jb.z, tc = cols / 64, t = blockIdx.x - jb.w, r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+  const float* s = src + jb.x + (int64_t)r0 * cols + c0;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;        // 16 threads x float4 per row, 16 rows per sweep
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(s + (int64_t)(ty + 16 * q) * cols + 4 * tx);
+    tile[ty + 16 * q][4 * tx] = v.x; tile[ty + 16 * q][4 * tx + 1] = v.y; tile[ty + 16 * q][4 * tx + 2] = v.z; tile[ty + 16 * q][4 * tx + 3] = v.w;
+  }
+  __syncthreads();
+  __bf16* d = dst + jb.x + (int64_t)c0 * rows + r0;              // dst[c][r]
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = ty + 16 * q;
+    const float4 v = make_float4(tile[4 * tx][c], tile[4 * tx + 1][c], tile[4 * tx + 2][c], tile[4 * tx + 3][c]);
+    IO<__bf16>::st4(d + (int64_t)c * rows + 4 * tx, v);
+  }
+}
+
 // Payload feature [B,4,64] tiled (1,16,8) into the first 512 channels of the bottleneck concat
 // [B,64,1024] (reference model.py:2389,2411) and the matching gradient fold.
 __global__ void msg_expand_fwd_kernel(const float* __restrict__ feat, float* __restrict__ dst, int64_t total) {
@@ -296,6 +326,14 @@ extern "C" int wm_cast_bf16(const float* src, void* dst, int64_t n, void* stream
   if (!src || !dst || n <= 0 || (n & 3) || !al16(src)) return WM_EINVAL;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), src,
                      static_cast<__bf16*>(dst), n / 4);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_transpose_cast_jobs(const float* arena, void* arena_t_bf16, const int32_t* jobs, int32_t njobs,
+                                      int32_t total_tiles, void* stream) {
+  if (!arena || !arena_t_bf16 || !jobs || njobs <= 0 || total_tiles <= 0) return WM_EINVAL;
+  hipLaunchKernelGGL(transpose_cast_jobs_kernel, dim3(total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), arena,
+                     static_cast<__bf16*>(arena_t_bf16), reinterpret_cast<const int4*>(jobs), njobs);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const DT* __restrict__ dy, 
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      float* __restrict__ dx, __bf16* __restrict__ dxh,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     float* __restrict__ part, int64_t rows) {
+                                                     float* __restrict__ part, int64_t rows,
+                                                     const float* __restrict__ hscale, int rows_per_scale) {
   constexpr int L = (C / 4 < 64) ? C / 4 : 64;
   constexpr int V = C / (4 * L);
   constexpr int RPW = 64 / L;
@@ -102,6 +103,8 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const DT* __restrict__ dy, 
   const int64_t stride = (int64_t)gridDim.x * LNB_WAVES * RPW;
   for (int64_t row = ((int64_t)blockIdx.x * LNB_WAVES + wave) * RPW + rg; row < rows; row += stride) {
     const float mu = mean[row], rs = rstd[row];
+    // the bf16 copy may carry the per-sample DropPath factor of the GEMMs that read it (dX and dW both want dy * s)
+    const float hs = hscale ? hscale[row / rows_per_scale] : 1.f;
     float4 xh[V], g[V], dr[V];
     float s1 = 0.f, s2 = 0.f;
     if (dres) {                                               // requested with the other operands, used after the reductions
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const DT* __restrict__ dy, 
       stream_store(dx + row * C + c, o);
       // the next GEMMs (dX, dW) round this gradient to bf16 while staging it anyway: a bf16 copy written here halves
       // what they read and lets them run as bf16 x bf16 instances (identical numbers)
-      if (dxh) IO<__bf16>::st4(dxh + row * C + c, o);
+      if (dxh) IO<__bf16>::st4(dxh + row * C + c, make_float4(o.x * hs, o.y * hs, o.z * hs, o.w * hs));
     }
   }
   // fold the RPW row groups of a wave (lanes sub, sub+L, ...) then the 4 waves
@@ -265,17 +268,17 @@ int ln_fwd_launch(const float* x, const float* g, const float* b, const float* m
 template <int C>
 int ln_bwd_launch(const void* dy, int dy_bf16, const float* x, const float* g, const float* mean, const float* rstd,
                   const float* dres, float* dx, __bf16* dxh, float* dg, float* db, float* scratch, WmReduceJob* defer, int64_t rows,
-                  hipStream_t st) {
+                  const float* hscale, int rows_per_scale, hipStream_t st) {
   constexpr int L = (C / 4 < 64) ? C / 4 : 64;
   constexpr int RPB = LNB_WAVES * (64 / L);
   int64_t blocks = (rows + RPB - 1) / RPB;
   if (blocks > 512) blocks = 512;
   if (dy_bf16)
     hipLaunchKernelGGL((ln_bwd_kernel<C, __bf16>), dim3((unsigned)blocks), dim3(512), 0, st,
-                       static_cast<const __bf16*>(dy), x, g, mean, rstd, dres, dx, dxh, dg, db, scratch, rows);
+                       static_cast<const __bf16*>(dy), x, g, mean, rstd, dres, dx, dxh, dg, db, scratch, rows, hscale, rows_per_scale);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<C, float>), dim3((unsigned)blocks), dim3(512), 0, st,
-                       static_cast<const float*>(dy), x, g, mean, rstd, dres, dx, dxh, dg, db, scratch, rows);
+                       static_cast<const float*>(dy), x, g, mean, rstd, dres, dx, dxh, dg, db, scratch, rows, hscale, rows_per_scale);
   WM_CHECK_LAUNCH();
   if (defer) {                                                // two entries: dgamma, dbeta
     WmReduceJob jb{};
@@ -324,17 +327,18 @@ extern "C" int64_t wm_layernorm_bwd_scratch_floats(int32_t C) { return 512LL * 2
 extern "C" int wm_layernorm_bwd(const void* dy, int32_t dy_bf16, const float* x, const float* gamma, const float* mean,
                                 const float* rstd, const float* dres, float* dx, void* dx_bf16, float* dgamma,
                                 float* dbeta, float* dmod, float* scratch, WmReduceJob* defer, int64_t rows, int32_t C,
-                                int32_t hw, int32_t shift, void* stream) {
+                                int32_t hw, int32_t shift, const float* copy_scale, int32_t rows_per_scale, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return WM_EINVAL;
+  if (copy_scale && (!dx_bf16 || rows_per_scale <= 0)) return WM_EINVAL;
   if (dmod && (hw <= 0 || (hw & 7) || rows % ((int64_t)hw * hw) || C < 64 || C > 1024)) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
   switch (C) {
-    case 32: rc = ln_bwd_launch<32>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, static_cast<__bf16*>(dx_bf16), dgamma, dbeta, scratch, defer, rows, st); break;
-    case 64: rc = ln_bwd_launch<64>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, static_cast<__bf16*>(dx_bf16), dgamma, dbeta, scratch, defer, rows, st); break;
-    case 128: rc = ln_bwd_launch<128>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, static_cast<__bf16*>(dx_bf16), dgamma, dbeta, scratch, defer, rows, st); break;
-    case 256: rc = ln_bwd_launch<256>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, static_cast<__bf16*>(dx_bf16), dgamma, dbeta, scratch, defer, rows, st); break;
-    case 512: rc = ln_bwd_launch<512>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, static_cast<__bf16*>(dx_bf16), dgamma, dbeta, scratch, defer, rows, st); break;
+    case 32: rc = ln_bwd_launch<32>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, static_cast<__bf16*>(dx_bf16), dgamma, dbeta, scratch, defer, rows, copy_scale, rows_per_scale, st); break;
+    case 64: rc = ln_bwd_launch<64>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, static_cast<__bf16*>(dx_bf16), dgamma, dbeta, scratch, defer, rows, copy_scale, rows_per_scale, st); break;
+    case 128: rc = ln_bwd_launch<128>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, static_cast<__bf16*>(dx_bf16), dgamma, dbeta, scratch, defer, rows, copy_scale, rows_per_scale, st); break;
+    case 256: rc = ln_bwd_launch<256>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, static_cast<__bf16*>(dx_bf16), dgamma, dbeta, scratch, defer, rows, copy_scale, rows_per_scale, st); break;
+    case 512: rc = ln_bwd_launch<512>(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, static_cast<__bf16*>(dx_bf16), dgamma, dbeta, scratch, defer, rows, copy_scale, rows_per_scale, st); break;
     default: return WM_EINVAL;
   }
   if (rc) return rc;

@@ -228,6 +228,7 @@ class UformerAudio(nn.Module):
         self._flat = torch.zeros(total + pad, device=device, dtype=torch.float32) if flat is None else flat
         self._flat_grad = torch.zeros(total + pad, device=device, dtype=torch.float32)
         self._flat_h = None                               # bf16 copy of the arena (GEMM B operands in bf16 mode)
+        self._flat_ht, self._tjobs = None, None           # transposed bf16 copies of the wide Linear weights (dX operands)
         self._views, self._gviews = {}, {}
         for name, shape, kind in self._specs:
             n, off = math.prod(shape), self._offsets[name]
@@ -323,12 +324,34 @@ class UformerAudio(nn.Module):
     def _attn_scratch(self, dev):
         return self._scratch(dev, ops.lib.wm_winattn_bwd_scratch_floats())
 
+    # Linear weights of the blocks with C >= BIG_C also get a TRANSPOSED bf16 copy per step: their dX products then run as
+    # K-contiguous x K-contiguous GEMMs on the 256 x 256 tile kernel (csrc/gemm_big.hip) like the forward ones
+    BIG_C = 256
+
+    def _transpose_jobs(self):
+        if self._tjobs is None or self._tjobs[0].device != self._flat.device:
+            rows, tile0 = [], 0
+            for name, shape, _ in self._specs:
+                if len(shape) == 2 and name.endswith(("attn.qkv.to_q.weight", "attn.proj.weight", "mlp.linear1.0.weight",
+                                                      "mlp.linear2.0.weight")) and min(shape) >= self.BIG_C:
+                    n, k = shape
+                    if name.endswith("to_q.weight"):
+                        n = 3 * n                                 # the fused [3C, C] q | kv operand (adjacent in the arena)
+                    rows.append((self._offsets[name], n, k, tile0))
+                    tile0 += (n // 64) * (k // 64)
+            self._tjobs = (torch.tensor(rows, dtype=torch.int32, device=self._flat.device).contiguous(), len(rows), tile0)
+        return self._tjobs
+
     def _refresh_weight_copy(self):
         if self.compute_mode != "bf16":
             return
         if self._flat_h is None or self._flat_h.device != self._flat.device:
             self._flat_h = torch.empty(self._flat.numel(), device=self._flat.device, dtype=torch.bfloat16)
+            self._flat_ht = torch.empty(self._flat.numel(), device=self._flat.device, dtype=torch.bfloat16)
         ops.cast_bf16(self._flat, self._flat_h, self._flat.numel())
+        jobs, njobs, tiles = self._transpose_jobs()
+        if njobs:
+            ops.transpose_cast_jobs(self._flat, self._flat_ht, jobs, njobs, tiles)
 
     def _W(self, name):
         """GEMM weight operand: fp32 parameter view, or its bf16 copy in bf16 mode."""
@@ -337,6 +360,14 @@ class UformerAudio(nn.Module):
             return v
         off = (v.data_ptr() - self._flat.data_ptr()) // 4
         return self._flat_h[off:off + v.numel()].view(v.shape)
+
+    def _WT(self, name):
+        """Transposed bf16 copy [in, out] of a wide Linear weight (bf16 mode, C >= BIG_C), else None."""
+        v = self._views[name]
+        if self.compute_mode != "bf16" or min(v.shape) < self.BIG_C:
+            return None
+        off = (v.data_ptr() - self._flat.data_ptr()) // 4
+        return self._flat_ht[off:off + v.numel()].view(v.shape[1], v.shape[0])
 
     def _ensure_runtime(self, device):
         if self._anchor is None or self._anchor.device != device:
@@ -423,9 +454,11 @@ class UformerAudio(nn.Module):
                        rowscale=s2, rows_per_scale=N)
         return x2, (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2, lse)
 
-    def _block_bwd(self, sv, dy, dyh=None):
+    def _block_bwd(self, sv, dy, dyh=None, consumer_scale=None):
         """Returns (dx, dxh): dxh is a bf16 copy of dx in bf16 mode (the next block's GEMM operand), else None.
-        dyh, if given, is such a copy of dy."""
+        dyh, if given, is such a copy of dy that ALREADY carries this block's second DropPath factor (the block that wrote
+        it was told so through ``consumer_scale``): the two fc2 products read dy * s2 and take no scale of their own.
+        ``consumer_scale``: the s2 of the block that will receive dxh (None: the copy stays unscaled)."""
         (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2, lse) = sv
         P, G, dev, mode = self._views, self._gviews, x.device, self._mode()
         M, N = x.shape[0], hw * hw
@@ -436,40 +469,52 @@ class UformerAudio(nn.Module):
         dh2 = H(dev, M, 4 * C)
         half = self.compute_mode == "bf16"
         dyg = dyh if dyh is not None else dy                       # GEMM operand: the bf16 copy when there is one
-        ops.linear_bwd_input(dyg, W(pre + "mlp.linear2.0.weight"), dh2, mode, rowscale=s2, rows_per_scale=N, gaux=h2, gaux_raw=True)
+        s2g = None if dyh is not None else s2                      # ... which already holds dy * s2
+        WT = self._WT
+        ops.linear_bwd_input(dyg, W(pre + "mlp.linear2.0.weight"), dh2, mode, rowscale=s2g, rows_per_scale=N, gaux=h2, gaux_raw=True,
+                             wT=WT(pre + "mlp.linear2.0.weight"))
         ops.linear_bwd_weight(dyg, a2, G[pre + "mlp.linear2.0.weight"], G[pre + "mlp.linear2.0.bias"], mode,
-                              kscale=s2, k_per_scale=N, scratch=sg0, defer=jobs.take(1))
+                              kscale=s2g, k_per_scale=N, scratch=sg0, defer=jobs.take(1))
         dh1 = H(dev, M, 4 * C)
         ops.dwconv_bwd(h1, dh2, P[pre + "mlp.dwconv.0.weight"], dh1, G[pre + "mlp.dwconv.0.weight"],
                        G[pre + "mlp.dwconv.0.bias"], B, hw, 4 * C, scratch=sdw, defer=jobs.take(2))
         dxn2 = H(dev, M, C)
-        ops.linear_bwd_input(dh1, W(pre + "mlp.linear1.0.weight"), dxn2, mode)
+        ops.linear_bwd_input(dh1, W(pre + "mlp.linear1.0.weight"), dxn2, mode, wT=WT(pre + "mlp.linear1.0.weight"))
         ops.linear_bwd_weight(dh1, xn2, G[pre + "mlp.linear1.0.weight"], G[pre + "mlp.linear1.0.bias"], mode, scratch=sg1,
                               defer=jobs.take(1))
         dx1 = _E(dev, M, C)
         dx1h = H(dev, M, C) if half else None
+        # the bf16 copy of dx1 feeds the two proj products only, both of which want dx1 * s1
         ops.layernorm_bwd(dxn2, x1, P[pre + "norm2.weight"], mean2, rstd2, dy, dx1, G[pre + "norm2.weight"],
-                          G[pre + "norm2.bias"], None, hw, 0, scratch=sl0, defer=jobs.take(2), dx_bf16=dx1h)
+                          G[pre + "norm2.bias"], None, hw, 0, scratch=sl0, defer=jobs.take(2), dx_bf16=dx1h,
+                          copy_scale=s1 if half else None, rows_per_scale=N)
         dx1g = dx1h if half else dx1
+        s1g = None if half else s1
         # attention
         do = dxn2                                                  # reuse buffer
-        ops.linear_bwd_input(dx1g, W(pre + "attn.proj.weight"), do, mode, rowscale=s1, rows_per_scale=N)
-        ops.linear_bwd_weight(dx1g, o, G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], mode, kscale=s1, k_per_scale=N,
+        ops.linear_bwd_input(dx1g, W(pre + "attn.proj.weight"), do, mode, rowscale=s1g, rows_per_scale=N, wT=WT(pre + "attn.proj.weight"))
+        ops.linear_bwd_weight(dx1g, o, G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], mode, kscale=s1g, k_per_scale=N,
                               scratch=sg2, defer=jobs.take(1))
         dqkv = H(dev, M, 3 * C)
         ops.winattn_bwd(qkv, P[pre + "attn.relative_position_bias_table"], do, dqkv,
                         G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, mode, out=o, lse=lse,
                         scratch=sat, defer=jobs.take(1))
         dxn1 = H(dev, M, C)
-        ops.linear_bwd_input(dqkv, W(pre + "attn.qkv.w"), dxn1, mode)
+        ops.linear_bwd_input(dqkv, W(pre + "attn.qkv.w"), dxn1, mode, wT=WT(pre + "attn.qkv.w"))
         ops.linear_bwd_weight(dqkv, xn1, G[pre + "attn.qkv.w"], G[pre + "attn.qkv.b"], mode, scratch=sg3, defer=jobs.take(1))
         dx = _E(dev, M, C)
         dxh = H(dev, M, C) if half else None
         ops.layernorm_bwd(dxn1, x, P[pre + "norm1.weight"], mean1, rstd1, dx1, dx, G[pre + "norm1.weight"],
                           G[pre + "norm1.bias"], G[pre + "modulator.weight"] if mod else None, hw, shift,
-                          scratch=sl1, defer=jobs.take(2), dx_bf16=dxh)
+                          scratch=sl1, defer=jobs.take(2), dx_bf16=dxh, copy_scale=consumer_scale if half else None,
+                          rows_per_scale=N)
         ops.reduce_jobs(jobs)
         return dx, dxh
+
+    @staticmethod
+    def _consumer_scale(items, k):
+        """s2 of the block that receives the gradient the k-th item of a reversed tape produces (None: no such block)."""
+        return items[k + 1][1][7] if k + 1 < len(items) and items[k + 1][0] == "block" else None
 
     def _down_fwd(self, pre, x, B, hw, C):
         P, dev, mode = self._views, x.device, self._mode()
@@ -571,7 +616,8 @@ class UformerAudio(nn.Module):
         G, P = self._gviews, self._views
         dy = dfeats[4] if dfeats is not None else None
         dyh = None                                                   # bf16 copy of dy while it comes straight out of a block
-        for item in reversed(tape):
+        items = list(reversed(tape))
+        for k, item in enumerate(items):
             kind = item[0]
             if kind == "conv2":
                 _, d2, x, z = item
@@ -584,7 +630,7 @@ class UformerAudio(nn.Module):
                 if dfeats is not None and dfeats[i] is not None:
                     ops.axpbyz(dy, 1.0, dy, 1.0, dfeats[i], dy.numel())
             elif kind == "block":
-                dy, dyh = self._block_bwd(item[1], dy, dyh)
+                dy, dyh = self._block_bwd(item[1], dy, dyh, self._consumer_scale(items, k))
             elif kind == "inproj":
                 _, d, img, y = item
                 dimg = _E(img.device, *img.shape)
@@ -754,9 +800,10 @@ class UformerAudio(nn.Module):
         ops.conv_bwd(d_out, ytok, P["output_proj.proj.0.weight"], noise, dy, dtok, G["output_proj.proj.0.weight"], G["output_proj.proj.0.bias"])
         dfe = [None] * 5
         g, gh = dtok, None
-        for item in reversed(S["dec"]):
+        ditems = list(reversed(S["dec"]))
+        for k, item in enumerate(ditems):
             if item[0] == "block":
-                g, gh = self._block_bwd(item[1], g, gh)
+                g, gh = self._block_bwd(item[1], g, gh, self._consumer_scale(ditems, k))
             else:
                 _, sv, i = item
                 g, dskip = self._up_bwd(sv, g)

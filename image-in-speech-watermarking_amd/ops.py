@@ -46,10 +46,16 @@ def linear_fwd(x, w, bias, out, mode, a_op=0, res=None, rowscale=None, rows_per_
          rows_per_scale=rows_per_scale, mode=mode)
 
 
-def linear_bwd_input(dy, w, dx, mode, rowscale=None, rows_per_scale=0, gaux=None, gaux_raw=False):
-    """dx[M,K] = ((dy[M,N] @ w[N,K]) * rowscale) * (gaux if gaux_raw else gelu'(gaux))"""
+def linear_bwd_input(dy, w, dx, mode, rowscale=None, rows_per_scale=0, gaux=None, gaux_raw=False, wT=None):
+    """dx[M,K] = ((dy[M,N] @ w[N,K]) * rowscale) * (gaux if gaux_raw else gelu'(gaux)).
+    wT (optional): the transposed copy w^T [K,N] (wm_transpose_cast_jobs); the product then runs as a K-contiguous x
+    K-contiguous GEMM like the forward, which is the form the 256 x 256 tile kernel takes."""
     M, N = dy.shape
     K = w.shape[1]
+    if wT is not None:
+        gemm(dy, wT, dx, M, K, N, N, N, K, 1, 1, rowscale=rowscale, rows_per_scale=rows_per_scale, gaux=gaux, ldg=K,
+             mode=mode, gaux_raw=gaux_raw)
+        return
     gemm(dy, w, dx, M, K, N, N, K, K, 1, 0, rowscale=rowscale, rows_per_scale=rows_per_scale, gaux=gaux, ldg=K,
          mode=mode, gaux_raw=gaux_raw)
 
@@ -68,14 +74,16 @@ def layernorm_fwd(x, gamma, beta, mod, y, mean, rstd, hw, shift):
                                hw, shift, _stream()), "wm_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dmod, hw, shift, scratch=None, defer=None, dx_bf16=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dmod, hw, shift, scratch=None, defer=None, dx_bf16=None,
+                  copy_scale=None, rows_per_scale=0):
     rows, Cc = x.shape
     if scratch is not None and scratch.numel() < lib.wm_layernorm_bwd_scratch_floats(Cc):
         raise ValueError("layernorm_bwd: scratch buffer too small")
     if dx_bf16 is not None and dx_bf16.dtype != torch.bfloat16:
         raise ValueError("layernorm_bwd: dx_bf16 must be a bfloat16 tensor")
     check(lib.wm_layernorm_bwd(ptr(dy), _bf(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx_bf16),
-                               ptr(dgamma), ptr(dbeta), ptr(dmod), ptr(scratch), defer, rows, Cc, hw, shift, _stream()),
+                               ptr(dgamma), ptr(dbeta), ptr(dmod), ptr(scratch), defer, rows, Cc, hw, shift, ptr(copy_scale),
+                               rows_per_scale, _stream()),
           "wm_layernorm_bwd")
 
 
@@ -140,6 +148,11 @@ def strided3(src, dst, n, si, so, atomic=False):
 
 def cast_bf16(src, dst, n):
     check(lib.wm_cast_bf16(ptr(src), ptr(dst), n, _stream()), "wm_cast_bf16")
+
+
+def transpose_cast_jobs(arena, arena_t, jobs, njobs, total_tiles):
+    """bf16 transposes of the job list's matrices (same offsets in both arenas), one launch."""
+    check(lib.wm_transpose_cast_jobs(ptr(arena), ptr(arena_t), ptr(jobs), njobs, total_tiles, _stream()), "wm_transpose_cast_jobs")
 
 
 def msg_expand_fwd(feat, dst, B):

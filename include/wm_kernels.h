@@ -77,11 +77,13 @@ int wm_layernorm_fwd(const float* x, const float* gamma, const float* beta, cons
  * scratch (optional, device, >= wm_layernorm_bwd_scratch_floats(C) floats, contents irrelevant): per-workgroup partial
  * sums of dgamma / dbeta, reduced by a second kernel; NULL = every workgroup adds with global atomics (slower).   */
 int64_t wm_layernorm_bwd_scratch_floats(int32_t C);
-/* dx_bf16 (optional): a bf16 copy of dx for the GEMMs that consume it next (they round it to bf16 anyway)           */
+/* dx_bf16 (optional): a bf16 copy of dx for the GEMMs that consume it next (they round it to bf16 anyway);
+ * copy_scale (optional, [rows / rows_per_scale]): the copy holds dx * copy_scale[sample] — the DropPath factor of the branch
+ * whose dX and dW products read it (reference model.py:1016-1017: x + drop_path(f(x))), so those launches need no scale */
 int wm_layernorm_bwd(const void* dy, int32_t dy_bf16, const float* x, const float* gamma, const float* mean,
                      const float* rstd, const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
                      float* dmod, float* scratch, WmReduceJob* defer /* 2 entries or NULL */, int64_t rows, int32_t C,
-                     int32_t hw, int32_t shift, void* stream);
+                     int32_t hw, int32_t shift, const float* copy_scale, int32_t rows_per_scale, void* stream);
 
 /* ---- 8x8 window attention — model.py:523-551 with roll/partition/reverse (:987-1013) and the
  * shift mask (:954-972) folded into the indexing.  qkv: [B*hw*hw, 3C] (q|k|v), heads of 32.    */
@@ -126,6 +128,12 @@ int wm_strided3(const float* in, void* out, int32_t out_bf16, int32_t n0, int32_
                 int64_t si1, int64_t si2, int64_t so0, int64_t so1, int64_t so2, int32_t atomic, void* stream);
 /* bf16 copy of (a slice of) the fp32 parameter arena: the B operands of the forward / dX GEMMs in bf16 mode */
 int wm_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* transposed bf16 copies of many [rows, cols] fp32 matrices of the parameter arena in one launch: the dX GEMMs of the
+ * 256 x 256 tile kernel (csrc/gemm_big.hip) take their weight K-contiguous, i.e. W^T of nn.Linear's [out, in] weight
+ * (model.py:460-471,549,700,711).  jobs (device, int32 x 4 per job, 16-byte aligned): {element offset of the matrix in BOTH
+ * arenas, rows, cols, index of the job's first 64 x 64 tile}; rows and cols are multiples of 64, offsets of 8. */
+int wm_transpose_cast_jobs(const float* arena, void* arena_t_bf16, const int32_t* jobs, int32_t njobs, int32_t total_tiles,
+                           void* stream);
 
 /* ---- small direct convolutions (InputProj :814, OutputProj :846, stft_layer :2305,
  * ConvAutoencoder :1700-1709, EncoderTransformerWM.conv2 :1566).  Layout flags: 0 = NCHW,
