@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "../../include/wm_kernels.h"
+#include "gemm_big_epi.h"
 
 namespace {
 
@@ -25,7 +26,6 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int ROWB = BK * 2;                       // bytes per LDS row
 constexpr int TILE_B = BM * ROWB;                  // 32 KB per operand tile
 constexpr int BUF_B = 2 * TILE_B;                  // A tile | B tile
-constexpr int LDC = BN + 4;                        // fp32 staging row of the epilogue
 constexpr int SMEM_B = 2 * BUF_B;                  // 128 KB (the epilogue's 64 x 260 fp32 image aliases it)
 
 #define WM_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0f70 | (n))      /* vmcnt(n), n <= 15; lgkmcnt / expcnt untouched */
@@ -115,58 +115,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const WmGemm g, con
     if (t + 2 < nt) request(t & 1);
   }
 
-  // ---- epilogue: four passes of 64 rows (tile row i of every wave) through a [64][260] fp32 image ----
-  float* Cs = reinterpret_cast<float*>(smem);
-  const int c4 = tid & 63, rg = tid >> 6, n = n0 + 4 * c4;
-  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + n);
-#pragma unroll                                                  // (a run-time index into acc[][] would put it in scratch memory)
-  for (int i = 0; i < 4; ++i) {
-    if (i) __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        Cs[(wm * 32 + mma32_row(e, h)) * LDC + wn * 64 + j * 32 + r] = acc[i][j][e];
-    __syncthreads();
-    // rows rg + 8 q of the image; q < 4: the wm = 0 half (global rows m0 + 32 i + ..), q >= 4: the wm = 1 half (+ 128)
-    int64_t grow[8];
-    float sc[2] = {1.f, 1.f};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) grow[q] = m0 + (q >> 2) * 128 + 32 * i + ((rg + 8 * q) & 31);
-    const bool ok0 = m0 + 32 * i < g.M, ok1 = m0 + 128 + 32 * i < g.M;     // M % 32 == 0 (host): a 32-row block is in or out
-    if (g.rowscale) {
-      if (ok0) sc[0] = g.rowscale[(m0 + 32 * i) / g.rows_per_scale];
-      if (ok1) sc[1] = g.rowscale[(m0 + 128 + 32 * i) / g.rows_per_scale];
-    }
-    uint2 ga[8];
-    float4 re[8];
-    if constexpr (EPI == 2) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (q < 4 ? ok0 : ok1) ga[q] = *reinterpret_cast<const uint2*>(static_cast<const __bf16*>(g.gaux) + grow[q] * g.ldg + n);
-    }
-    if constexpr (EPI == 1) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (q < 4 ? ok0 : ok1) re[q] = *reinterpret_cast<const float4*>(g.res + grow[q] * g.ldr + n);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if (!(q < 4 ? ok0 : ok1)) continue;
-      const float s = sc[q >> 2];
-      float4 v = *reinterpret_cast<const float4*>(Cs + (rg + 8 * q) * LDC + 4 * c4);
-      if constexpr (EPI == 1) {
-        v.x = (v.x + bias4.x) * s + re[q].x; v.y = (v.y + bias4.y) * s + re[q].y;
-        v.z = (v.z + bias4.z) * s + re[q].z; v.w = (v.w + bias4.w) * s + re[q].w;
-        stream_store(static_cast<float*>(g.C) + grow[q] * g.ldc + n, v);
-      } else {
-        if constexpr (EPI == 0) { v.x = (v.x + bias4.x) * s; v.y = (v.y + bias4.y) * s; v.z = (v.z + bias4.z) * s; v.w = (v.w + bias4.w) * s; }
-        else { v.x *= s * bf_lo(ga[q].x); v.y *= s * bf_hi(ga[q].x); v.z *= s * bf_lo(ga[q].y); v.w *= s * bf_hi(ga[q].y); }
-        stream_store(static_cast<__bf16*>(g.C) + grow[q] * g.ldc + n, make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)));
-      }
-    }
-  }
+  bigtile::nt_epilogue<EPI>(acc, g, m0, n0, smem, tid, wm, wn, r, h);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -317,20 +266,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const WmGemm g, con
     if (t + 2 < nt) request(t & 1);
   }
 
-  // slice (or, for a single k range, the running sum in C) as plain stores: 128-byte row segments per half wave
-  float* const dst = part ? part + (int64_t)bz * g.M * g.N : static_cast<float*>(g.C);
-  const int64_t ldd = part ? g.N : g.ldc;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float* d = dst + (int64_t)(m0 + wm * 128 + i * 32 + 4 * h) * ldd + n0 + wn * 64 + j * 32 + r;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        if (part) *d = acc[i][j][e]; else *d += acc[i][j][e];
-        d += ((e & 3) == 3) ? 5 * ldd : ldd;                     // rows (e & 3) + 8 (e >> 2) + 4 h
-      }
-    }
+  bigtile::tn_store(acc, g, part, bz, m0, n0, wm, wn, r, h);
   if (do_bias) {
     bsum += __shfl_xor(bsum, 32);                                 // the two k halves of the fragment
     if (h == 0) atomicAdd(g.C2 + m0 + wm * 128 + wn * 32 + r, bsum);
@@ -354,6 +290,14 @@ int launch_nt_big(const WmGemm& g, hipStream_t st) {
 
 }  // namespace
 
+// gemm_pp.hip: the same tiles on the ping-pong schedule (the default); WM_GEMM_BIG_V=1 selects the kernels of this file
+int wm_gemm_pp_nt_launch(const WmGemm& g, int epi, hipStream_t st);
+int wm_gemm_pp_tn_launch(const WmGemm& g, int klen, int tiles_n, int tiles_m, int ksplit, float* part, hipStream_t st);
+static bool use_pp() {
+  const char* v = getenv("WM_GEMM_BIG_V");
+  return !(v && v[0] == '1');
+}
+
 // Returns -1 when the launch does not fit (the caller goes on to the 128 x 128 kernels).
 int wm_gemm_big_bf16(const WmGemm& g, hipStream_t st) {
   const char* off = getenv("WM_GEMM_BIG_OFF");                    // A/B switch for the microbenchmarks (read per call: host side, ~50 ns)
@@ -364,10 +308,13 @@ int wm_gemm_big_bf16(const WmGemm& g, hipStream_t st) {
   if (tiles < 256) return -1;                                     // fewer tiles than CUs: the small tiles fill the chip better
   if (g.rowscale && (g.rows_per_scale % 32)) return -1;
   if (!al16(g.A) || !al16(g.B) || !al16(g.C) || (g.ldc % 8) || (g.bias && !al16(g.bias))) return -1;
-  if (g.c_bf16 && !g.gaux && !g.res) return launch_nt_big<0>(g, st);
-  if (!g.c_bf16 && g.res && !g.gaux && al16(g.res) && !(g.ldr % 4)) return launch_nt_big<1>(g, st);
-  if (g.c_bf16 && g.gaux && g.gaux_raw && g.gaux_bf16 && !g.res && !g.bias && al16(g.gaux) && !(g.ldg % 8)) return launch_nt_big<2>(g, st);
-  return -1;
+  int epi = -1;
+  if (g.c_bf16 && !g.gaux && !g.res) epi = 0;
+  else if (!g.c_bf16 && g.res && !g.gaux && al16(g.res) && !(g.ldr % 4)) epi = 1;
+  else if (g.c_bf16 && g.gaux && g.gaux_raw && g.gaux_bf16 && !g.res && !g.bias && al16(g.gaux) && !(g.ldg % 8)) epi = 2;
+  if (epi < 0) return -1;
+  if (use_pp()) return wm_gemm_pp_nt_launch(g, epi, st);
+  return epi == 0 ? launch_nt_big<0>(g, st) : epi == 1 ? launch_nt_big<1>(g, st) : launch_nt_big<2>(g, st);
 }
 
 // Weight gradient dW[M,N] (+)= A[K,M]^T B[K,N] on 256 x 256 tiles, split over the token range so that about one workgroup per
@@ -410,8 +357,13 @@ int wm_gemm_big_tn_bf16(const WmGemm& g, hipStream_t st) {
     attr = true;
   }
   float* part = ksplit > 1 ? g.scratch : nullptr;
-  hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(8 * ((ksplit + 7) / 8) * tiles), dim3(512), SMEM_B, st, g, klen, tiles_n, tiles_m, ksplit, part);
-  WM_CHECK_LAUNCH();
+  if (use_pp()) {
+    const int rc = wm_gemm_pp_tn_launch(g, klen, tiles_n, tiles_m, ksplit, part, st);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(8 * ((ksplit + 7) / 8) * tiles), dim3(512), SMEM_B, st, g, klen, tiles_n, tiles_m, ksplit, part);
+    WM_CHECK_LAUNCH();
+  }
   if (g.defer) {
     WmReduceJob jb{};
     if (part) {
