@@ -52,6 +52,10 @@ def parse_args():
                     help="capture the step as the multi-rank chain of graphs (cut at the gradient buckets) on one rank too")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline and the BER / deviation parity block)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--ber-train-steps", type=int, default=1600,
+                    help="trained-state BER leg: train a fresh model for this many captured steps (B = 32, config 3) on the synthetic "
+                         "stream, then compare the decoded payload of the HIP path and of the CPU oracle on the trained weights "
+                         "(0: skip; skipped with --no-cpu-baseline)")
     ap.add_argument("--detail", action="store_true", help="per-shape GEMM timing table on stderr")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="run the N-rank code path with every rank on GPU 0 over gloo (a functional rehearsal on a one-GPU "
@@ -60,12 +64,36 @@ def parse_args():
 
 
 # ---------------------------------------------------------------------------------------------------- launcher
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT starting the HIP runtime (the parent of the rank processes must never touch
+    a GPU): the visibility variables if set, else the KFD topology (nodes with SIMDs are GPUs)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    n, root = 0, "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return None                                              # unknown: let the ranks report a shortage themselves
+    return n
+
+
 def launch_ranks(a):
-    """Parent of a plain `python bench.py --gpus N` call: starts N rank processes (fresh interpreters, so nothing here
-    has initialised a GPU), relays rank 0's stdout, returns the worst exit code."""
-    import torch
-    if not a.rehearse_one_gpu and torch.cuda.device_count() < a.gpus:      # device_count() does not initialise the GPU
-        raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible "
+    """Parent of a plain `python bench.py --gpus N` call: starts N rank processes (fresh interpreters; this process never
+    initialises a GPU), relays rank 0's JSON line and every rank's stderr, and returns the first non-zero exit code — when a
+    rank dies the others are terminated instead of waiting in a collective until the distributed timeout."""
+    if any(k.startswith("ROCPROF") or k.startswith("ROCPROFILER") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        raise SystemExit("bench.py --gpus N under rocprofv3: the profiler's preload has already initialised the GPU in this "
+                         "process, starting rank programs from it is the forbidden hop; profile one rank directly "
+                         "(rocprofv3 ... -- python3 bench.py --gpus 1 ...)")
+    have = visible_gpus()
+    if not a.rehearse_one_gpu and have is not None and have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible "
                          "(use --rehearse-one-gpu for a functional rehearsal of the N-rank path on one GPU)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -75,15 +103,37 @@ def launch_ranks(a):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))   # stderr: inherited, every rank
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = abs(bad[0][1]) or 1
+            print(f"bench.py: rank {bad[0][0]} exited with code {bad[0][1]}; stopping the other ranks", file=sys.stderr)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
     # rank 0 prints ONE JSON line; libraries may add their own chatter to its stdout (gloo announces its peers in the one-GPU
     # rehearsal): relay the JSON line alone, the rest goes to stderr
-    for line in out.decode().splitlines():
+    for line in (out[0] if out else b"").decode().splitlines():
         (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return failed
 
 
 # ---------------------------------------------------------------------------------------------------- workload
@@ -348,6 +398,8 @@ def main():
         result["allreduce"] = allreduce
     if rank == 0 and world == 1 and not a.no_kernel_timing:
         kernel_rooflines(a, wm, net, opt, attack, extract_from, x, msg, result)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.ber_train_steps > 0 and a.clip_seconds == 1:
+        result["ber_trained"] = trained_ber(wm, a)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(attacked)
         result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
@@ -355,6 +407,23 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def trained_ber(wm, a):
+    """Matched decoder BER on weights that actually decode (the `ber` block above is the untrained synthetic init, BER 0.5 on
+    both sides): tests/ber_train.py trains a fresh model with the HIP TrainStep in the benched mode, the fp32 CPU oracle gets
+    the same weights and both decode held-out (tile, payload) pairs.  Weights live in this process only."""
+    import ber_train
+    t0 = time.perf_counter()
+    net, curve, xh, mh = ber_train.train(wm, a.ber_train_steps, batch=32, mode=a.mode, lr=2e-4, eval_every=max(a.ber_train_steps // 4, 1))
+    t1 = time.perf_counter()
+    out = {"trained": f"{a.ber_train_steps} captured steps of B = 32, config 3 (full attack stack, extractor on the attacked spectrogram), "
+                      f"{a.mode}, AdamW lr 2e-4, synthetic chirp tiles scaled 0.05, payloads = 8 x 8 random bits as 4 x 4 blocks",
+           "train_seconds": round(t1 - t0, 1),
+           "ber_curve_held_out": [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in e.items() if k != "loss_terms"} for e in curve],
+           "oracle_parity": ber_train.oracle_parity(wm, net, xh, mh, tiles=8)}
+    out["oracle_seconds"] = round(time.perf_counter() - t1, 1)
+    return out
 
 
 def kernel_rooflines(a, wm, net, opt, attack, extract_from, x, msg, result):

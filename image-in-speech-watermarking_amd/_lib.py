@@ -71,6 +71,9 @@ _SIGS = {
     "wm_strided3": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_f],
     "wm_cast_bf16": [c_f, c_f, c_i64, c_f],
     "wm_transpose_cast_jobs": [c_f, c_f, c_f, c_i32, c_i32, c_f],
+    "wm_minmax_scratch_floats": [],
+    "wm_minmax": [c_f, c_i64, c_f, c_f, c_f],
+    "wm_range_map": [c_f, c_f, c_f, c_fl, c_fl, c_i32, c_i64, c_f],
     "wm_msg_expand_fwd": [c_f, c_f, c_i32, c_f],
     "wm_msg_expand_bwd": [c_f, c_f, c_i32, c_f],
     "wm_conv_fwd": [C.POINTER(WmConv), c_f, c_f, c_f, c_f, c_f],
@@ -115,6 +118,7 @@ _SIGS = {
     "wm_jpeg_mask": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_adamw": [c_f, c_f, c_f, c_f, c_i64, c_f, c_fl, c_fl, c_fl, c_fl, c_f, c_f, c_f],
     "wm_step_inc": [c_f, c_f],
+    "wm_step_copy": [c_f, c_f, c_f],
     "wm_droppath_scales": [c_f, c_f, c_i32, c_i32, c_u64, c_f, c_f],
     "wm_zero": [c_f, c_i64, c_f],
     "wm_axpbyz": [c_f, c_fl, c_f, c_fl, c_f, c_i64, c_f],

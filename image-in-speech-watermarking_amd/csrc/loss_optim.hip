@@ -83,6 +83,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 __global__ void step_inc_kernel(int64_t* step) { *step += 1; }
+__global__ void step_copy_kernel(const int64_t* src, int64_t* dst) { *dst = *src; }
 __global__ void zero_small_kernel(float* p, int n) {
   if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
 }
@@ -158,6 +159,12 @@ extern "C" int wm_adamw(float* p, const float* g, float* m, float* v, int64_t n,
 extern "C" int wm_step_inc(int64_t* step, void* stream) {
   if (!step) return WM_EINVAL;
   hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), step);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_step_copy(const int64_t* src, int64_t* dst, void* stream) {
+  if (!src || !dst) return WM_EINVAL;
+  hipLaunchKernelGGL(step_copy_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), src, dst);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

@@ -174,6 +174,46 @@ __global__ __launch_bounds__(256) void transpose_cast_jobs_kernel(const float* _
   }
 }
 
+// Range-style audio_scale of the reference's data preparation (audio_test.py:33-55 normalize_batch, :331-338, :559-571):
+// min / max over a whole tile tensor, then an affine map into [lo, hi] (or back).  Two launches for the reduction (per-block
+// partials, then one block), the statistics stay on the device.
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
+  float lo = INFINITY, hi = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i];
+    lo = fminf(lo, v); hi = fmaxf(hi, v);
+  }
+  __shared__ float sl[256], sh[256];
+  sl[threadIdx.x] = lo; sh[threadIdx.x] = hi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { sl[threadIdx.x] = fminf(sl[threadIdx.x], sl[threadIdx.x + o]); sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = sl[0]; part[2 * blockIdx.x + 1] = sh[0]; }
+}
+__global__ __launch_bounds__(256) void minmax_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
+  float lo = INFINITY, hi = -INFINITY;
+  for (int i = threadIdx.x; i < nb; i += 256) { lo = fminf(lo, part[2 * i]); hi = fmaxf(hi, part[2 * i + 1]); }
+  __shared__ float sl[256], sh[256];
+  sl[threadIdx.x] = lo; sh[threadIdx.x] = hi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { sl[threadIdx.x] = fminf(sl[threadIdx.x], sl[threadIdx.x + o]); sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = sl[0]; out[1] = sh[0]; }
+}
+// forward: out = (x - min) / (max - min) * (hi - lo) + lo      inverse: out = (x - lo) / (hi - lo) * (max - min) + min
+__global__ void range_map_kernel(const float* __restrict__ x, float* __restrict__ out, const float* __restrict__ mm, float lo, float hi,
+                                 int inverse, int64_t n) {
+  const float dmin = mm[0], dmax = mm[1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    out[i] = inverse ? (v - lo) / (hi - lo) * (dmax - dmin) + dmin : (v - dmin) / (dmax - dmin) * (hi - lo) + lo;
+  }
+}
+
 // Payload feature [B,4,64] tiled (1,16,8) into the first 512 channels of the bottleneck concat
 // [B,64,1024] (reference model.py:2389,2411) and the matching gradient fold.
 __global__ void msg_expand_fwd_kernel(const float* __restrict__ feat, float* __restrict__ dst, int64_t total) {
@@ -334,6 +374,26 @@ extern "C" int wm_transpose_cast_jobs(const float* arena, void* arena_t_bf16, co
   if (!arena || !arena_t_bf16 || !jobs || njobs <= 0 || total_tiles <= 0) return WM_EINVAL;
   hipLaunchKernelGGL(transpose_cast_jobs_kernel, dim3(total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), arena,
                      static_cast<__bf16*>(arena_t_bf16), reinterpret_cast<const int4*>(jobs), njobs);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int64_t wm_minmax_scratch_floats(void) { return 2 * 1024; }
+extern "C" int wm_minmax(const float* x, int64_t n, float* out_min_max, float* scratch, void* stream) {
+  if (!x || n <= 0 || !out_min_max || !scratch) return WM_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int nb = (int)((n + 256 * 16 - 1) / (256 * 16));
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb), dim3(256), 0, st, x, n, scratch);
+  WM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, st, scratch, nb, out_min_max);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_range_map(const float* x, float* out, const float* min_max, float lo, float hi, int32_t inverse, int64_t n,
+                            void* stream) {
+  if (!x || !out || !min_max || n <= 0 || hi == lo) return WM_EINVAL;
+  hipLaunchKernelGGL(range_map_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, min_max, lo, hi,
+                     inverse, n);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

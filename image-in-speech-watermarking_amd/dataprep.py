@@ -21,6 +21,41 @@ def stft_tiles(wave, scale=1.0):
     return tiles, tiles.shape[0] // wave.shape[0]
 
 
+def parse_audio_scale(audio_scale):
+    """The reference's string option (options.py --audio_scale; audio_test.py:40-47): '0' / one character -> None (leave the
+    tiles alone), a plain number of more than one character -> ('factor', f), 'lo-hi' -> ('range', lo, hi)."""
+    audio_scale = str(audio_scale)
+    if "-" in audio_scale:
+        lo, hi = audio_scale.split("-")
+        return ("range", float(lo), float(hi))
+    return ("factor", float(audio_scale)) if len(audio_scale) > 1 else None
+
+
+def _stats(data_min, data_max, device):
+    """data_min / data_max as the reference passes them around (python floats, 0-d or 1-element tensors) -> [min, max] on device."""
+    if torch.is_tensor(data_min) and data_min.numel() == 2 and data_max is None:
+        return data_min.to(device).float().contiguous()
+    f = lambda v: v.reshape(-1)[:1].to(device).float() if torch.is_tensor(v) else torch.tensor([float(v)], device=device)
+    return torch.cat([f(data_min), f(data_max)]).contiguous()
+
+
+def normalize_tiles(tiles, audio_scale, data_min=None, data_max=None):
+    """normalize_batch of audio_test.py:33-55 on the device: returns (tiles', data_min, data_max).  Range form: min / max over
+    the WHOLE tensor (unless given: the evaluation sets pass the training set's, audio_test.py:338), then the affine map into
+    [lo, hi]; factor form: tiles * f; both statistics come back as 1-element device tensors (no host synchronisation)."""
+    mode = parse_audio_scale(audio_scale)
+    tiles = tiles.contiguous().float()
+    mm = ops.minmax(tiles) if data_min is None else _stats(data_min, data_max, tiles.device)
+    if mode is None:
+        out = tiles
+    elif mode[0] == "factor":
+        out = torch.empty_like(tiles)
+        ops.axpbyz(out, mode[1], tiles, 0.0, None, tiles.numel())
+    else:
+        out = ops.range_map(tiles, mm, mode[1], mode[2])
+    return out, mm[0:1], mm[1:2]
+
+
 def split_payload(img):
     """[B, 1, 64, 64] -> [B, 4, 1, 32, 32]: quadrants in row-major order (top-left, top-right, bottom-left, bottom-right)."""
     if img.dim() != 4 or img.shape[1:] != (1, 64, 64):

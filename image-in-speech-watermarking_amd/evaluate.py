@@ -1,5 +1,6 @@
-"""Whole-utterance evaluation path on the device: the ``data_mode='stft'`` branch of the
-reference's ``SpeechDataTest.prepare_data`` (audio_test.py:299-343) and ``reconstruct_audio`` (audio_test.py:528-785).
+"""Whole-utterance evaluation path on the device: the ``data_mode='stft'`` and ``'audio'`` branches
+of the reference's ``SpeechDataTest`` / ``SpeechDataAudio.prepare_data`` (audio_test.py:299-343, :135-153) and
+``reconstruct_audio`` (audio_test.py:528-785), every ``audio_scale`` form included ('0', a factor, the 'lo-hi' range).
 
 Same call surface and return tuple as the reference; what changes is where the work runs:
 
@@ -17,19 +18,34 @@ import torch
 from . import ops
 
 
-def prepare_utterance(wave, audio_scale="0"):
-    """One entry of SpeechDataTest.prepare_data: ``[wave, clips, len_last_clip]`` with clips ``[n, 2, 128, 128]``.
+def prepare_utterance(wave, audio_scale="0", data_min=None, data_max=None, data_mode="stft"):
+    """One entry of SpeechDataTest.prepare_data: ``[wave, clips, len_last_clip]`` with clips ``[n, 2, 128, 128]``
+    (``data_mode='audio'``: SpeechDataAudio.prepare_data, audio_test.py:135-153 — the waveform zero-padded to a multiple of
+    128 * 128 samples and cut into ``[n, 1, 128, 128]`` clips; the pad is a FULL clip when the length already divides).
 
     ``audio_scale``: the reference's string option; a plain number of more than one character scales the tiles
-    (audio_test.py:327-330), '0' leaves them alone; the 'min-max' range form needs dataset-wide statistics the path
-    does not hold and is rejected."""
-    if "-" in audio_scale:
-        raise ValueError("range-style audio_scale needs dataset statistics (audio_test.py:331-337): not on this path")
+    (audio_test.py:327-330), '0' leaves them alone, 'lo-hi' maps them from [data_min, data_max] — the training set's
+    statistics (dataprep.normalize_tiles returns them; audio_test.py:331-338) — into [lo, hi]."""
+    from .dataprep import parse_audio_scale, _stats
     if wave.dim() == 1:
         wave = wave[None]
     if wave.dim() != 2 or wave.shape[0] != 1 or not wave.is_cuda:
         raise ValueError("prepare_utterance takes one CUDA waveform [1, L]")
-    scale = float(audio_scale) if len(audio_scale) > 1 else 1.0
+    if data_mode == "audio":
+        L = wave.shape[-1]
+        len_pad = 128 * 128 - L % (128 * 128)
+        clips = torch.nn.functional.pad(wave.float(), (0, len_pad)).view(-1, 1, 128, 128).contiguous()
+        return [wave, clips, 128 * 128 - len_pad]
+    if data_mode != "stft":
+        raise ValueError("data_mode 'dwt' needs pywt (a CPU library outside the hot path); 'stft' and 'audio' run here")
+    mode = parse_audio_scale(audio_scale)
+    if mode is not None and mode[0] == "range":
+        if data_min is None or data_max is None:
+            raise ValueError("range-style audio_scale maps from the training set's [data_min, data_max] (audio_test.py:338): pass them")
+        clips, frames = ops.stft255_tiles(wave.contiguous().float(), 1.0)
+        clips = ops.range_map(clips, _stats(data_min, data_max, wave.device), mode[1], mode[2])
+        return [wave, clips, frames % 128]
+    scale = mode[1] if mode is not None else 1.0
     clips, frames = ops.stft255_tiles(wave.contiguous().float(), scale)
     return [wave, clips, frames % 128]
 
@@ -168,15 +184,63 @@ def _db(r):
 
 
 @torch.no_grad()
+def _run_model(model, model_name, clips, msg, batch):
+    """audio_test.py:547-556, batched over tiles: (encoded clips, decoded payloads)."""
+    enc, dec = [], []
+    for i in range(0, clips.shape[0], batch):
+        c = clips[i:i + batch].contiguous()
+        m = msg.expand(c.shape[0], 1, 32, 32).contiguous()
+        if model_name == "uformer":
+            audio_clip, _, _, wm_decode = model(c, m)
+        else:                                                              # 'modelA' convention: (encoded, extracted)
+            audio_clip, wm_decode = model(c, m)
+        enc.append(audio_clip)
+        dec.append(wm_decode)
+    return torch.cat(enc).contiguous(), torch.cat(dec)
+
+
+def _decode(model, c):
+    """audio_test.py:706-708, :763-766: ``wm_decode`` where the model has one, else ``decode``."""
+    return model.wm_decode(c) if hasattr(model, "wm_decode") else model.decode(c)
+
+
+def _reconstruct_audio_mode(audio_datas, watermark, model, attack, model_name, batch, seed):
+    """``data_mode='audio'`` (audio_test.py:581-583, :601-606, :665-670, :733-772): raw-sample clips [n, 1, 128, 128]."""
+    U = len(audio_datas)
+    L, n, len_last = audio_datas[0][0].shape[-1], audio_datas[0][1].shape[0], int(audio_datas[0][2])
+    if any(d[0].shape[-1] != L for d in audio_datas):
+        raise ValueError("reconstruct_audio_batch takes utterances of equal length")
+    waves = torch.cat([d[0].reshape(1, -1) for d in audio_datas]).contiguous().float()
+    msg = watermark.reshape(1, 1, 32, 32).float()
+    enc, dec = _run_model(model, model_name, torch.cat([d[1] for d in audio_datas]).contiguous(), msg, batch)
+    recon_audio = enc.reshape(U, n * 128 * 128)[:, :(n - 1) * 128 * 128 + len_last].contiguous()       # last clip trimmed
+    audio_att = _attack(recon_audio, attack, seed)
+    La = audio_att.shape[-1]
+    len_pad = 128 * 128 - La % (128 * 128)
+    att_clips = torch.nn.functional.pad(audio_att.float(), (0, len_pad)).reshape(-1, 1, 128, 128).contiguous()
+    n_att = att_clips.shape[0] // U
+    dec_att = torch.cat([_decode(model, att_clips[i:i + batch].contiguous()) for i in range(0, att_clips.shape[0], batch)])
+    return waves, recon_audio, audio_att, dec, dec_att, n, n_att
+
+
+@torch.no_grad()
 def reconstruct_audio_batch(audio_datas, watermark, model, n_fft=255, attack=None, data_mode="stft", audio_scale="0",
-                            model_name="uformer", batch=96, seed=0):
+                            model_name="uformer", batch=96, seed=0, data_min=None, data_max=None):
     """``reconstruct_audio`` for several utterances of EQUAL length in one pass: their tiles share the model batches
     (the model is 1.5 x more efficient at 96 tiles than at 20), the transforms and attacks take [U, L] waveforms, and
     all scalar metrics come back in one host read.  Returns one reference-style 10-tuple per utterance."""
+    from .dataprep import parse_audio_scale, _stats
+    if data_mode == "audio":
+        waves, recon_audio, audio_att, dec, dec_att, n, n_att = _reconstruct_audio_mode(audio_datas, watermark, model, attack,
+                                                                                        model_name, batch, seed)
+        return _metrics(waves, recon_audio, audio_att, watermark, dec, dec_att, n, n_att)
     if data_mode != "stft" or n_fft != 255:
-        raise ValueError("the MI355X evaluation path covers data_mode='stft' with n_fft=255 (audio_test.py:594-600)")
-    if "-" in audio_scale:
-        raise ValueError("range-style audio_scale needs dataset statistics: not on this path")
+        raise ValueError("the MI355X evaluation path covers data_mode='stft' (n_fft=255, audio_test.py:594-600) and 'audio'; "
+                         "'dwt' needs pywt, a CPU library outside the hot path")
+    mode = parse_audio_scale(audio_scale)
+    ranged = mode is not None and mode[0] == "range"
+    if ranged and (data_min is None or data_max is None):
+        raise ValueError("range-style audio_scale needs the training set's data_min / data_max (audio_test.py:567-571)")
     U = len(audio_datas)
     L, n, len_last_clip = audio_datas[0][0].shape[-1], audio_datas[0][1].shape[0], int(audio_datas[0][2])
     if any(d[0].shape[-1] != L or d[1].shape[0] != n or int(d[2]) != len_last_clip for d in audio_datas):
@@ -184,30 +248,29 @@ def reconstruct_audio_batch(audio_datas, watermark, model, n_fft=255, attack=Non
     waves = torch.cat([d[0].reshape(1, -1) for d in audio_datas]).contiguous()
     clips = torch.cat([d[1] for d in audio_datas]).contiguous()
     msg = watermark.reshape(1, 1, 32, 32).float()
-    enc, dec = [], []
-    for i in range(0, U * n, batch):                                      # audio_test.py:547-556, batched over tiles
-        c = clips[i:i + batch].contiguous()
-        m = msg.expand(c.shape[0], 1, 32, 32).contiguous()
-        if model_name == "uformer":
-            audio_clip, _, _, wm_decode = model(c, m)
-        elif model_name == "modelA":
-            audio_clip, wm_decode = model(c, m)
-        else:
-            raise ValueError(f"unknown model_name '{model_name}'")
-        enc.append(audio_clip)
-        dec.append(wm_decode)
-    enc, dec = torch.cat(enc).contiguous(), torch.cat(dec)
-    factor = 1.0 / float(audio_scale) if len(audio_scale) > 1 else 1.0    # :559-563
+    if model_name not in ("uformer", "modelA"):
+        raise ValueError(f"unknown model_name '{model_name}'")
+    enc, dec = _run_model(model, model_name, clips, msg, batch)
+    if ranged:                                                            # :567-571: back to the spectrogram's own range
+        mm = _stats(data_min, data_max, waves.device)
+        enc = ops.range_map(enc, mm, mode[1], mode[2], inverse=True)
+    factor = 1.0 / mode[1] if (mode is not None and mode[0] == "factor") else 1.0     # :559-566
     recon_audio = ops.istft255_stitch(enc, n, len_last_clip, L, factor)   # :594-600, [U, L]
     audio_att = _attack(recon_audio, attack, seed)                        # :628-660
-    scale = float(audio_scale) if len(audio_scale) > 1 else 1.0
+    scale = mode[1] if (mode is not None and mode[0] == "factor") else 1.0
     att_clips, _ = ops.stft255_tiles(audio_att.contiguous(), scale)       # :676-700
+    if ranged:
+        att_clips = ops.range_map(att_clips, mm, mode[1], mode[2])        # :698-702
     n_att = att_clips.shape[0] // U
-    dec_att = []
-    for i in range(0, att_clips.shape[0], batch):
-        c = att_clips[i:i + batch].contiguous()
-        dec_att.append(model.wm_decode(c) if model_name == "uformer" else model.decode(c))
-    dec_att = torch.cat(dec_att)
+    dec_att = torch.cat([model.wm_decode(att_clips[i:i + batch].contiguous()) if model_name == "uformer"
+                         else model.decode(att_clips[i:i + batch].contiguous()) for i in range(0, att_clips.shape[0], batch)])
+    return _metrics(waves, recon_audio, audio_att, watermark, dec, dec_att, n, n_att)
+
+
+def _metrics(waves, recon_audio, audio_att, watermark, dec, dec_att, n, n_att):
+    """The reference's 10-tuple per utterance; all scalar metrics in one host read."""
+    U = waves.shape[0]
+    msg = watermark.reshape(1, 1, 32, 32).float()
     scal = torch.zeros(U, 2 + n_att, device=waves.device)                 # mse_loss | wm_loss | wm_losses_att...
     for u in range(U):
         _mse(waves[u:u + 1], recon_audio[u:u + 1], scal[u, 0])            # :618
@@ -227,9 +290,10 @@ def reconstruct_audio_batch(audio_datas, watermark, model, n_fft=255, attack=Non
 @torch.no_grad()
 def reconstruct_audio(audio_data, watermark, model, n_fft=255, attack=None, data_mode="stft", audio_scale="0",
                       data_min=None, data_max=None, model_name="uformer", batch=32, seed=0):
-    """reconstruct_audio of audio_test.py:528-785 for ``data_mode='stft'``.
+    """reconstruct_audio of audio_test.py:528-785 for ``data_mode='stft'`` and ``'audio'``.
 
     Returns ``(audio_att, recon_audio, watermark, wms_decode, wms_att_decode, mse_loss, wm_loss, wm_loss_att,
     snr_ori, snr_recon)``: tensors stay on the device, the per-tile lists hold ``[1, 1, 32, 32]`` tensors."""
     return reconstruct_audio_batch([audio_data], watermark, model, n_fft=n_fft, attack=attack, data_mode=data_mode,
-                                   audio_scale=audio_scale, model_name=model_name, batch=batch, seed=seed)[0]
+                                   audio_scale=audio_scale, model_name=model_name, batch=batch, seed=seed,
+                                   data_min=data_min, data_max=data_max)[0]

@@ -740,13 +740,18 @@ class UformerAudio(nn.Module):
         wave = _E(dev, B, WAVE_LEN)
         ops.istft_fwd(yw, wave, B)
         att = attack if (attack is not None and attack.flags) else None
+        step_used = None
         if att is not None:
-            wave_a, sigma = attack_forward(att, wave, self._step_t)
+            # the backward replays the AWGN / jitter draws from (seed, step): keep THIS pass's step value (a second training
+            # forward before this pass's backward advances the live counter)
+            step_used = torch.empty_like(self._step_t)
+            ops.step_copy(self._step_t, step_used)
+            wave_a, sigma = attack_forward(att, wave, step_used)
         else:
             wave_a, sigma = wave, None
         spec = _E(dev, B, 2, 128, 128)
         ops.stft_fwd(wave_a, spec, B)
-        S["stft"] = (att, wave, sigma)
+        S["stft"] = (att, wave, sigma, step_used)
         c1 = ops.conv_desc(B, 2, 128, 128, 4, (3, 3), (1, 1), (1, 1), act="relu")
         mid = _E(dev, B, 4, 128, 128)
         ops.conv_fwd(c1, spec, P["stft_layer.0.weight"], P["stft_layer.0.bias"], mid)
@@ -783,11 +788,11 @@ class UformerAudio(nn.Module):
             after_segment(0)                                        # extractor + stft_layer gradients are final
         if S["extract_from"] != "y":
             ops.axpbyz(dspec, 1.0, dspec, 1.0, d_src, dspec.numel())
-        att, wave, sigma = S["stft"]
+        att, wave, sigma, step_used = S["stft"]
         dwave = _E(dev, B, WAVE_LEN)
         ops.stft_bwd(dspec, dwave, B)
         if att is not None:
-            dwave = attack_backward(att, wave, dwave, sigma, self._step_t)
+            dwave = attack_backward(att, wave, dwave, sigma, step_used)
         dy = _E(dev, B, 2, 128, 128)
         ops.istft_bwd(dwave, dy, B)
         if S["extract_from"] == "y":

@@ -155,6 +155,23 @@ def transpose_cast_jobs(arena, arena_t, jobs, njobs, total_tiles):
     check(lib.wm_transpose_cast_jobs(ptr(arena), ptr(arena_t), ptr(jobs), njobs, total_tiles, _stream()), "wm_transpose_cast_jobs")
 
 
+def minmax(x):
+    """[min, max] of a float32 tensor as a 2-element device tensor (no host synchronisation)."""
+    x = x.contiguous()
+    out = torch.empty(2, device=x.device)
+    scr = torch.empty(int(lib.wm_minmax_scratch_floats()), device=x.device)
+    check(lib.wm_minmax(ptr(x), x.numel(), ptr(out), ptr(scr), _stream()), "wm_minmax")
+    return out
+
+
+def range_map(x, min_max, lo, hi, inverse=False):
+    """(x - min) / (max - min) * (hi - lo) + lo, or its inverse, with device-resident statistics."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(lib.wm_range_map(ptr(x), ptr(out), ptr(min_max), float(lo), float(hi), int(inverse), x.numel(), _stream()), "wm_range_map")
+    return out
+
+
 def msg_expand_fwd(feat, dst, B):
     check(lib.wm_msg_expand_fwd(ptr(feat), ptr(dst), B, _stream()), "wm_msg_expand_fwd")
 
@@ -312,6 +329,10 @@ def adamw(p, g, m, v, n, lr_t, b1, b2, eps, wd, step_t, gscale_t=None):
 
 def step_inc(step_t):
     check(lib.wm_step_inc(ptr(step_t), _stream()), "wm_step_inc")
+
+
+def step_copy(src, dst):
+    check(lib.wm_step_copy(ptr(src), ptr(dst), _stream()), "wm_step_copy")
 
 
 def droppath_scales(scales, rates, nslots, B, seed, step_t):

@@ -128,6 +128,13 @@ int wm_strided3(const float* in, void* out, int32_t out_bf16, int32_t n0, int32_
                 int64_t si1, int64_t si2, int64_t so0, int64_t so1, int64_t so2, int32_t atomic, void* stream);
 /* bf16 copy of (a slice of) the fp32 parameter arena: the B operands of the forward / dX GEMMs in bf16 mode */
 int wm_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* Range-style audio_scale ("lo-hi") of the reference's data preparation and evaluation loop: min / max over the whole tile
+ * tensor (normalize_batch, audio_test.py:33-55) left on the device, and the affine map of a tensor into [lo, hi] with those
+ * statistics (audio_test.py:331-338, :698-702) or back (inverse != 0; audio_test.py:567-571).
+ * scratch: >= wm_minmax_scratch_floats() floats, contents irrelevant; out_min_max / min_max: 2 floats (min, max). */
+int64_t wm_minmax_scratch_floats(void);
+int wm_minmax(const float* x, int64_t n, float* out_min_max, float* scratch, void* stream);
+int wm_range_map(const float* x, float* out, const float* min_max, float lo, float hi, int32_t inverse, int64_t n, void* stream);
 /* transposed bf16 copies of many [rows, cols] fp32 matrices of the parameter arena in one launch: the dX GEMMs of the
  * 256 x 256 tile kernel (csrc/gemm_big.hip) take their weight K-contiguous, i.e. W^T of nn.Linear's [out, in] weight
  * (model.py:460-471,549,700,711).  jobs (device, int32 x 4 per job, 16-byte aligned): {element offset of the matrix in BOTH
@@ -260,6 +267,9 @@ int wm_tv_pow_fwd_bwd(const float* x, int32_t N, int32_t C, int32_t H, int32_t W
 int wm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, float beta1, float beta2,
              float eps, float wd, const int64_t* step, const float* grad_scale, void* stream);
 int wm_step_inc(int64_t* step, void* stream);
+/* *dst = *src on the stream: a forward pass keeps the step value its random draws (AWGN, jitter positions) were keyed with, so
+ * that its backward replays the same draws even if another training forward has advanced the counter in between */
+int wm_step_copy(const int64_t* src, int64_t* dst, void* stream);
 int wm_droppath_scales(float* scales, const float* rates, int32_t nslots, int32_t B, uint64_t seed,
                        const int64_t* step, void* stream);
 /* p[0..n) = 0 (16-byte aligned p): per-step clear of the gradient arena and of accumulation targets               */

@@ -6,6 +6,7 @@
 set -o pipefail
 R=${1:-r02}; shift
 ARGS="$@"
+case " $ARGS " in *" --gpus "*) echo "gpu_profile.sh profiles ONE rank: drop --gpus (a self-launching bench under rocprofv3 is the forbidden hop)"; exit 2;; esac
 B=256; MODE=bf16; ATT=full
 set -- $ARGS
 while [ $# -gt 0 ]; do case $1 in --batch) B=$2; shift;; --mode) MODE=$2; shift;; --attack) ATT=$2; shift;; esac; shift; done

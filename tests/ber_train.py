@@ -31,11 +31,12 @@ def block_payloads(n, gen, device="cpu"):
     return bits.repeat_interleave(4, 2).repeat_interleave(4, 3).contiguous().to(device)
 
 
-def tile_pool(wm, n, dev, tag="ber"):
-    """n synthetic speech-like STFT tiles through the device data-prep path."""
+def tile_pool(wm, n, dev, tag="ber", scale=1.0):
+    """n synthetic speech-like STFT tiles through the device data-prep path; `scale` as the reference's
+    audio_scale factor (audio_test.py:44-55 scales the tiles into a unit-ish range before training)."""
     from synth import chirp_wave
     waves = torch.stack([chirp_wave(16384 - 128, f"{tag}_{i}") for i in range(n)]).to(dev)
-    tiles, n_per = wm.dataprep.stft_tiles(waves)
+    tiles, n_per = wm.dataprep.stft_tiles(waves, scale)
     return tiles.view(n, n_per, 2, 128, 128)[:, 0].contiguous()
 
 
@@ -62,7 +63,7 @@ def evaluate(wm, net, x, msg):
     return out
 
 
-def train(wm, steps, batch=32, mode="bf16", lr=2e-4, eval_every=50, pool=256, held_out=16, seed=0, log=None):
+def train(wm, steps, batch=32, mode="bf16", lr=2e-4, eval_every=50, pool=256, held_out=16, seed=0, log=None, scale=0.05):
     """Fresh UformerAudio (its own default initialisation, torch seed `seed`) trained for `steps` captured steps of config 3.
     Returns (net, curve, held-out x, held-out payloads)."""
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -74,7 +75,7 @@ def train(wm, steps, batch=32, mode="bf16", lr=2e-4, eval_every=50, pool=256, he
     opt = wm.FusedAdamW(net, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
     step = wm.TrainStep(net, opt, batch, attack=wm.AttackConfig(**FULL_STACK), extract_from="attacked")
     gen = torch.Generator().manual_seed(seed + 1)
-    tiles = tile_pool(wm, pool + held_out, dev)
+    tiles = tile_pool(wm, pool + held_out, dev, scale=scale)
     xh, mh = tiles[pool:].contiguous(), block_payloads(held_out, torch.Generator().manual_seed(seed + 2), dev)
     curve = []
     for it in range(steps + 1):
@@ -155,11 +156,13 @@ def main():
     ap.add_argument("--lr", type=float, default=2e-4)
     ap.add_argument("--eval-every", type=int, default=50)
     ap.add_argument("--mode", default="bf16")
+    ap.add_argument("--scale", type=float, default=0.05)
     ap.add_argument("--no-oracle", action="store_true")
     a = ap.parse_args()
     wm = importlib.import_module("image-in-speech-watermarking_amd")
-    net, curve, xh, mh = train(wm, a.steps, a.batch, a.mode, a.lr, a.eval_every, log=lambda e: print(json.dumps(e), file=sys.stderr, flush=True))
-    res = {"steps": a.steps, "batch": a.batch, "lr": a.lr, "mode": a.mode, "curve": curve}
+    net, curve, xh, mh = train(wm, a.steps, a.batch, a.mode, a.lr, a.eval_every, scale=a.scale,
+                               log=lambda e: print(json.dumps(e), file=sys.stderr, flush=True))
+    res = {"steps": a.steps, "batch": a.batch, "lr": a.lr, "mode": a.mode, "tile_scale": a.scale, "curve": curve}
     if not a.no_oracle:
         res["oracle_parity"] = oracle_parity(wm, net, xh, mh, 8)
     print(json.dumps(res))

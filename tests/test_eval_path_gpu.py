@@ -232,4 +232,82 @@ def test_out_of_path_attacks_raise(wm):
     with pytest.raises(NotImplementedError):
         wm.evaluate._attack(wave, "mp3compress-64k", 0)
     with pytest.raises(ValueError):
-        wm.evaluate.prepare_utterance(wave, "0.01-0.1")
+        wm.evaluate.prepare_utterance(wave, "0.01-0.1")                            # range form without the statistics
+    with pytest.raises(ValueError):
+        wm.evaluate.prepare_utterance(wave, "0", data_mode="dwt")
+
+
+@pytest.mark.parametrize("scale", ["0.01-0.1", "10", "0"])
+def test_normalize_tiles_matches_normalize_batch(wm, scale):
+    """normalize_batch (audio_test.py:33-55) on the device: the three audio_scale forms, statistics left on the device."""
+    tiles = synth_array("nb_tiles", (5, 2, 128, 128), 3.0) + 0.7
+    ref, mn, mx = E.normalize_batch(tiles, scale)
+    out, dmin, dmax = wm.dataprep.normalize_tiles(tiles.cuda(), scale)
+    assert dmin.item() == mn.item() and dmax.item() == mx.item()
+    assert rel(out, ref) <= 1e-6
+    # evaluation-side use: the training set's statistics are passed in (audio_test.py:338)
+    out2, _, _ = wm.dataprep.normalize_tiles(tiles.cuda()[:2], scale, dmin, dmax)
+    assert rel(out2, ref[:2]) <= 1e-6
+
+
+def test_reconstruct_audio_range_scale_matches_oracle_loop(wm):
+    """'lo-hi' audio_scale through the whole loop: tiles mapped into the range on the way in, back on the way out, and again
+    for the re-analysis (audio_test.py:331-338, :567-571, :698-702)."""
+    net = wm.UformerAudio(modulator=True)
+    load_synth(net)
+    net = net.cuda().eval()
+    net.compute_mode = "fp32"
+    ref_net = O.UformerAudio().eval()
+    ref_net.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    L, scale, dmin, dmax = 12000, "0.01-0.5", -31.5, 40.25
+    wave = torch.as_tensor(chirp_wave(L, "rng"), dtype=torch.float32).reshape(1, L)
+    msg = synth_bits("rng_msg", (1, 1, 32, 32))
+    r = E.reconstruct_audio(E.prepare_utterance(wave, scale, dmin, dmax), msg, ref_net, lambda x: x * 0.9, scale, dmin, dmax)
+    data = wm.evaluate.prepare_utterance(wave.cuda(), scale, dmin, dmax)
+    assert rel(data[1], E.prepare_utterance(wave, scale, dmin, dmax)[1]) <= 2e-4
+    g = wm.evaluate.reconstruct_audio(data, msg.cuda(), net, attack="amplitude_scaling-0.9", audio_scale=scale,
+                                      data_min=dmin, data_max=torch.tensor([dmax]))
+    assert rel(g[1], r[1]) <= 1e-3 and rel(g[0], r[0]) <= 1e-3
+    for a, b in zip(g[3] + g[4], r[3] + r[4]):
+        assert rel(a, b) <= 1e-3
+    for i in (5, 6, 7):
+        assert abs(g[i] - r[i]) <= 1e-3 * max(abs(r[i]), 1e-6), (i, g[i], r[i])
+
+
+@pytest.mark.parametrize("L", [40000, 32768])
+def test_reconstruct_audio_raw_sample_mode(wm, L):
+    """data_mode='audio' (audio_test.py:135-153, :601-606, :733-772): raw-sample [1,128,128] clips through a model with the
+    modelA call convention (encoded, extracted) + .decode — here the HiDDeN decoder (hidden/model/decoder.py) behind a fixed
+    additive embedder; L = 32768 exercises the reference's full extra clip of padding (len_last_clip = 0)."""
+    import torch.nn.functional as F
+
+    class Toy:
+        def __init__(self, dec):
+            self.dec = dec
+
+        def __call__(self, clip, m):
+            enc = clip + 0.01 * F.interpolate(m, scale_factor=4.0)
+            return enc, self.dec(enc)
+
+        def decode(self, c):
+            return self.dec(c)
+    dec = wm.small_models.HiddenDecoder()
+    load_synth(dec)
+    dec = dec.cuda().eval()
+    ref_dec = O.HiddenDecoder().eval()
+    ref_dec.load_state_dict({k: v.cpu() for k, v in dec.state_dict().items()})
+    wave = torch.as_tensor(chirp_wave(L, "raw"), dtype=torch.float32).reshape(1, L)
+    msg = synth_bits("raw_msg", (1, 1, 32, 32))
+    with torch.no_grad():
+        r = E.reconstruct_audio_raw(E.prepare_utterance_audio(wave), msg, Toy(ref_dec), lambda x: x * 0.8)
+    data = wm.evaluate.prepare_utterance(wave.cuda(), data_mode="audio")
+    ref_data = E.prepare_utterance_audio(wave)
+    assert data[2] == ref_data[2] and torch.equal(data[1].cpu(), ref_data[1])
+    g = wm.evaluate.reconstruct_audio(data, msg.cuda(), Toy(dec), attack="amplitude_scaling-0.8", data_mode="audio",
+                                      model_name="modelA")
+    assert g[1].shape[-1] == L and rel(g[1], r[1]) <= 1e-6 and rel(g[0], r[0]) <= 1e-6
+    assert len(g[3]) == len(r[3]) and len(g[4]) == len(r[4])
+    for a, b in zip(g[3] + g[4], r[3] + r[4]):
+        assert rel(a, b) <= 1e-4
+    for i in (5, 6, 7):
+        assert abs(g[i] - r[i]) <= 1e-4 * max(abs(r[i]), 1e-9), (i, g[i], r[i])

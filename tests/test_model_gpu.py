@@ -441,3 +441,33 @@ def test_training_forward_advances_the_random_streams(wm):
     with torch.no_grad():
         e, f = m2(x, msg)[0].clone(), m2(x, msg)[0].clone()
     assert not torch.equal(e, f)                                 # AWGN realisation differs per step
+
+
+def test_backward_replays_its_own_forwards_noise_draw(wm):
+    """Two training forwards, then their two backwards (gradient accumulation over two graphs, or net(x2) before
+    loss1.backward()): every backward must regenerate the AWGN / jitter draws of ITS forward, not of the latest one.  The sum
+    of the two gradients equals the sum from the interleaved order forward-backward-forward-backward."""
+    cfg = wm.AttackConfig(snr_db=10.0, jitter=200, amp=0.9)
+
+    def grads(interleaved):
+        m = wm.UformerAudio(modulator=True, drop_path_rate=0.0, attack=cfg, extract_from="attacked", compute_mode="fp32")
+        load_synth(m)
+        m = m.cuda().train()
+        x1, m1 = synth_tile(2, "nd_x1").cuda(), synth_bits("nd_m1", (2, 1, 32, 32)).cuda()
+        x2, m2 = synth_tile(2, "nd_x2").cuda(), synth_bits("nd_m2", (2, 1, 32, 32)).cuda()
+        m._flat_grad.zero_()
+        o1 = m(x1, m1)
+        l1 = ((o1[0] - x1) ** 2).mean() + ((o1[3] - m1) ** 2).mean()
+        if interleaved:
+            l1.backward()
+        o2 = m(x2, m2)
+        l2 = ((o2[0] - x2) ** 2).mean() + ((o2[3] - m2) ** 2).mean()
+        if not interleaved:
+            l1.backward()
+        l2.backward()
+        return m._flat_grad.clone(), o1[0].detach().clone(), o2[0].detach().clone()
+    ga, a1, a2 = grads(True)
+    gb, b1, b2 = grads(False)
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)            # same draws in both orders
+    err = ((ga - gb).norm() / ga.norm()).item()
+    assert err <= 1e-5, err                                      # fp32 atomics reorder sums; a wrong draw gives O(1e-1)
