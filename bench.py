@@ -72,6 +72,8 @@ def visible_gpus():
         if v is not None:
             return len([t for t in v.split(",") if t.strip() != ""])
     n, root = 0, "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(root):
+        return 0                                                 # no AMD GPU driver on this machine
     try:
         for node in os.listdir(root):
             with open(os.path.join(root, node, "properties")) as f:
@@ -344,6 +346,7 @@ def main():
     dt = timed(step, x, msg, a.steps, max(a.warmup, 2))           # >= 2: first call warms up + captures the graph
     losses = step.losses.cpu().tolist()
     used_graph, segmented = step.use_graph, step.segmented
+    n_graphs = len(step._segments[0]) if step._segments else 1
     allreduce = None
     if world > 1:
         # per-bucket gradient all-reduce time on the side stream (3 more steps; events on the communication stream)
@@ -352,12 +355,17 @@ def main():
             step.step(x, msg)
         barrier()
         per = {}
-        for idx, s, e in step.sync.timing:
-            per.setdefault(idx, []).append(s.elapsed_time(e))
+        for lo, hi, s, e in step.sync.timing:
+            per.setdefault((lo, hi), []).append(s.elapsed_time(e))
         step.sync.timing = None
-        mb = [b.numel() * 4 / 1e6 for b in net.grad_buckets()]
-        allreduce = [{"bucket": ("extractor", "decoder", "encoder")[i], "MB": round(mb[i], 1),
-                      "ms": round(statistics.median(per[i]), 3)} for i in sorted(per)]
+        # bus bandwidth of a ring all-reduce: 2 (N - 1) / N x bytes / time; one xGMI link carries ~153 GB/s per direction pair
+        # (MI355X_MICROARCH / SURVEY 5), so a ring is bound by that per link
+        allreduce = {"buckets_in_launch_order": [
+            {"MB": round((hi - lo) * 4 / 1e6, 1), "ms": round(statistics.median(t), 3),
+             "bus_GBps": round(2 * (world - 1) / world * (hi - lo) * 4 / (statistics.median(t) * 1e-3) / 1e9, 1)}
+            for (lo, hi), t in per.items()],
+            "xgmi_link_GBps": 153, "bucket_target_MB": round(step.sync.bucket_elems * 4 / 2 ** 20, 1),
+            "exposed_tail_MB": round(sum((hi - lo) for (lo, hi) in list(per)[-2:]) * 4 / 1e6, 1)}
     # the captured step holds 0.56 GB per tile; the legs below build their own steps at the same batch: give the memory back first
     step.release()
     ref_batch = identity = None
@@ -385,7 +393,7 @@ def main():
                    "baseline_config": 5 if a.clip_seconds == 10 else (3 if attacked else 2),
                    "tiles_per_gpu": a.batch, "global_tiles": world * a.batch, "audio_sec_per_tile": TILE_SECONDS,
                    "parallelism": f"dp{world}", "graph": used_graph,
-                   "graph_segments": (4 if segmented else 1) if used_graph else 0, "params_M": 68.71},
+                   "graph_segments": (n_graphs if segmented else 1) if used_graph else 0, "params_M": 68.71},
         "loss_terms": losses[:5],
     }
     if ref_batch is not None:

@@ -30,7 +30,9 @@ class WmGemm(C.Structure):
                 ("b_ones", c_i32), ("C2", c_f),
                 ("atomic_out", c_i32), ("ksplit", c_i32), ("mode", c_i32),
                 ("a_bf16", c_i32), ("b_bf16", c_i32), ("c_bf16", c_i32), ("gaux_bf16", c_i32),
-                ("gaux_raw", c_i32), ("scratch", c_f), ("scratch_floats", c_i64), ("defer", C.POINTER(WmReduceJob))]
+                ("gaux_raw", c_i32), ("scratch", c_f), ("scratch_floats", c_i64), ("defer", C.POINTER(WmReduceJob)),
+                ("ln_gamma", c_f), ("ln_beta", c_f), ("ln_mod", c_f), ("ln_out", c_f), ("ln_mean", c_f), ("ln_rstd", c_f),
+                ("ln_hw", c_i32), ("ln_shift", c_i32)]
 
 
 class WmConv(C.Structure):
@@ -53,6 +55,7 @@ _SIGS = {
     "wm_abi_version": [],
     "wm_gemm_scratch_floats": [],
     "wm_gemm": [C.POINTER(WmGemm), c_f],
+    "wm_gemm_ln_fusable": [c_i32, c_i32, c_i32, c_i32, c_i32],
     "wm_layernorm_fwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f],
     "wm_layernorm_bwd_scratch_floats": [c_i32],
     "wm_reduce_jobs": [C.POINTER(WmReduceJob), c_i32, c_f],

@@ -579,6 +579,18 @@ extern "C" int wm_abi_version(void) { return 4; }
 // per CU (256 x 65536 floats = 67 MB)
 extern "C" int64_t wm_gemm_scratch_floats(void) { return 256LL * 256 * 256 + 1024 * 1024; }
 
+// The LayerNorm of the output rows can ride in the epilogue when a tile holds whole rows: N = 32 / 64 / 128 on the 128 x 128
+// family (any row count that is a multiple of 256), N = 256 on the 256 x 256 tiles (which need at least 256 of them)
+extern "C" int32_t wm_gemm_ln_fusable(int32_t M, int32_t N, int32_t K, int32_t mode, int32_t a_bf16) {
+  if (mode != 1 || !a_bf16 || M <= 0 || (M % 256) || K < 8 || (K % 8)) return 0;
+  if (N == 32 || N == 64 || N == 128) return 1;
+  if (N == 256) {
+    const char* off = getenv("WM_GEMM_BIG_OFF");
+    return (K % 64) == 0 && K >= 128 && (M / 256) >= 256 && !(off && off[0] == '1');
+  }
+  return 0;
+}
+
 extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
   if (!gp) return WM_EINVAL;
   const WmGemm& g = *gp;
@@ -595,6 +607,12 @@ extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
   if (g.kscale && (g.k_per_scale <= 0 || (g.k_per_scale & 3))) return WM_EINVAL;
   if (g.rowscale && g.rows_per_scale <= 0) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (g.ln_out) {                                              // fused LayerNorm: only the kernels that hold whole rows
+    if (g.mode != 1 || !g.ln_gamma || !g.ln_beta || !g.ln_mean || !g.ln_rstd || !wm_gemm_ln_fusable(g.M, g.N, g.K, g.mode, g.a_bf16))
+      return WM_EINVAL;
+    int rc = g.N == 256 ? wm_gemm_big_bf16(g, st) : wm_gemm_fast_bf16(g, st);
+    return rc >= 0 ? rc : WM_EINVAL;
+  }
   if (g.mode == 0) return dispatch<float, float, float, false, 32>(g, g.ksplit, st);
   if (g.mode == 1) {
     int rc = wm_gemm_big_bf16(g, st);

@@ -309,12 +309,17 @@ int wm_gemm_big_bf16(const WmGemm& g, hipStream_t st) {
   if (g.rowscale && (g.rows_per_scale % 32)) return -1;
   if (!al16(g.A) || !al16(g.B) || !al16(g.C) || (g.ldc % 8) || (g.bias && !al16(g.bias))) return -1;
   int epi = -1;
-  if (g.c_bf16 && !g.gaux && !g.res) epi = 0;
+  if (g.ln_out) {                                                 // fused LayerNorm of whole output rows: one column tile
+    if (g.N != BN || (g.M % BM) || g.c_bf16 || !g.res || g.gaux || !al16(g.res) || (g.ldr % 4) || !al16(g.ln_gamma) ||
+        !al16(g.ln_beta) || !al16(g.ln_out) || (g.ln_mod && (!al16(g.ln_mod) || g.ln_hw <= 0)))
+      return -1;
+    epi = 4;
+  } else if (g.c_bf16 && !g.gaux && !g.res) epi = 0;
   else if (!g.c_bf16 && g.res && !g.gaux && al16(g.res) && !(g.ldr % 4)) epi = 1;
   else if (g.c_bf16 && g.gaux && g.gaux_raw && g.gaux_bf16 && !g.res && !g.bias && al16(g.gaux) && !(g.ldg % 8)) epi = 2;
   if (epi < 0) return -1;
   if (use_pp()) return wm_gemm_pp_nt_launch(g, epi, st);
-  return epi == 0 ? launch_nt_big<0>(g, st) : epi == 1 ? launch_nt_big<1>(g, st) : launch_nt_big<2>(g, st);
+  return epi == 0 ? launch_nt_big<0>(g, st) : epi == 1 ? launch_nt_big<1>(g, st) : epi == 2 ? launch_nt_big<2>(g, st) : launch_nt_big<4>(g, st);
 }
 
 // Weight gradient dW[M,N] (+)= A[K,M]^T B[K,N] on 256 x 256 tiles, split over the token range so that about one workgroup per

@@ -10,6 +10,8 @@ namespace bigtile {
 constexpr int LDC = 256 + 4;                        // fp32 staging row of the epilogue
 
 //   EPI 0: C(bf16) = (acc + bias) * sc          EPI 1: C(fp32) = (acc + bias) * sc + res          EPI 2: C(bf16) = acc * sc * gaux(bf16)
+//   EPI 4: EPI 1 + LayerNorm of the finished rows (N == 256: the 64 threads = one wave of a staging row hold all of it), as in
+//          gemm_fast.hip (host: M % 256 == 0, so no row of a tile is outside the matrix)
 // smem: at least 64 * LDC floats, free of other use (every wave has passed a barrier after its last operand read)
 template <int EPI>
 __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[4][2], const WmGemm& g, int m0, int n0, char* smem, int tid, int wm, int wn,
@@ -45,10 +47,55 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[4][2], const WmGemm& g
       for (int q = 0; q < 8; ++q)
         if (q < 4 ? ok0 : ok1) ga[q] = *reinterpret_cast<const uint2*>(static_cast<const __bf16*>(g.gaux) + grow[q] * g.ldg + n);
     }
-    if constexpr (EPI == 1) {
+    if constexpr (EPI == 1 || EPI == 4) {
 #pragma unroll
       for (int q = 0; q < 8; ++q)
         if (q < 4 ? ok0 : ok1) re[q] = *reinterpret_cast<const float4*>(g.res + grow[q] * g.ldr + n);
+    }
+    if constexpr (EPI == 4) {
+      const float4 gm = *reinterpret_cast<const float4*>(g.ln_gamma + n), bt = *reinterpret_cast<const float4*>(g.ln_beta + n);
+      float4 v[8];
+      float s1[8], s2[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float s = sc[q >> 2];
+        float4 x = *reinterpret_cast<const float4*>(Cs + (rg + 8 * q) * LDC + 4 * c4);
+        x.x = (x.x + bias4.x) * s + re[q].x; x.y = (x.y + bias4.y) * s + re[q].y;
+        x.z = (x.z + bias4.z) * s + re[q].z; x.w = (x.w + bias4.w) * s + re[q].w;
+        stream_store(static_cast<float*>(g.C) + grow[q] * g.ldc + n, x);
+        v[q] = x;
+        s1[q] = (x.x + x.y) + (x.z + x.w);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s1[q] += __shfl_xor(s1[q], o);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float mu = s1[q] * (1.0f / 256.0f);
+        s1[q] = mu;
+        v[q].x -= mu; v[q].y -= mu; v[q].z -= mu; v[q].w -= mu;
+        s2[q] = (v[q].x * v[q].x + v[q].y * v[q].y) + (v[q].z * v[q].z + v[q].w * v[q].w);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s2[q] += __shfl_xor(s2[q], o);
+      const int64_t img = (int64_t)g.ln_hw * g.ln_hw;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float rs = 1.0f / sqrtf(s2[q] * (1.0f / 256.0f) + 1e-5f);
+        float4 o = make_float4(v[q].x * rs * gm.x + bt.x, v[q].y * rs * gm.y + bt.y, v[q].z * rs * gm.z + bt.z, v[q].w * rs * gm.w + bt.w);
+        if (g.ln_mod) {
+          const int t = (int)(grow[q] % img), yy = t / g.ln_hw, xx = t - yy * g.ln_hw;
+          const int pi = (yy - g.ln_shift + g.ln_hw) % g.ln_hw, pj = (xx - g.ln_shift + g.ln_hw) % g.ln_hw;
+          const float4 mm = *reinterpret_cast<const float4*>(g.ln_mod + (int64_t)((pi & 7) * 8 + (pj & 7)) * 256 + n);
+          o.x += mm.x; o.y += mm.y; o.z += mm.z; o.w += mm.w;
+        }
+        stream_store(static_cast<__bf16*>(g.ln_out) + grow[q] * 256 + n, make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w)));
+        if (c4 == 0) { g.ln_mean[grow[q]] = s1[q]; g.ln_rstd[grow[q]] = rs; }
+      }
+      continue;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {

@@ -192,9 +192,68 @@ __device__ __forceinline__ bool tile_of_block(int tiles_n, int tiles_m, int kspl
 //   EPI 0: C(bf16) = (acc + bias) * sc                       (qkv / fc1 forward, plain dX, proj dX with DropPath scale)
 //   EPI 1: C(fp32) = (acc + bias) * sc + res                 (proj / fc2 forward with DropPath scale and residual)
 //   EPI 2: C(bf16) = acc * sc * gaux(bf16 factor)            (fc2 dX times the stored gelu')
-template <int EPI, int NR, int RPP, int LDC>
+//   EPI 4: EPI 1 + the LayerNorm of the finished row (N == the tile width: the TPRW threads of a row hold all of it) written as
+//          bf16 with its statistics: norm2 behind proj, the next block's norm1 (+ window modulator) behind fc2
+__device__ __forceinline__ int ln_window_pos(int t, int hw, int shift) {      // t = token index inside its image
+  const int yy = t / hw, xx = t - yy * hw;
+  const int i = (yy - shift + hw) % hw, j = (xx - shift + hw) % hw;
+  return (i & 7) * 8 + (j & 7);
+}
+template <int EPI, int NR, int RPP, int LDC, int TPRW = 32>
 __device__ __forceinline__ void epi_interior(const float* cs, const WmGemm& g, int64_t row0, int n, float4 bias4, float sc) {
   const int64_t cstep = (int64_t)RPP * g.ldc;
+  if constexpr (EPI == 4) {
+    float4 re[NR], v[NR];
+    {
+      const float* rp = g.res + row0 * g.ldr + n;
+      const int64_t rstep = (int64_t)RPP * g.ldr;
+#pragma unroll
+      for (int q = 0; q < NR; ++q, rp += rstep) re[q] = *reinterpret_cast<const float4*>(rp);
+    }
+    const float4 gm = *reinterpret_cast<const float4*>(g.ln_gamma + n), bt = *reinterpret_cast<const float4*>(g.ln_beta + n);
+    float* cf = static_cast<float*>(g.C) + row0 * g.ldc + n;
+    float s1[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q, cf += cstep) {
+      float4 x = *reinterpret_cast<const float4*>(cs + q * RPP * LDC);
+      x.x = (x.x + bias4.x) * sc + re[q].x; x.y = (x.y + bias4.y) * sc + re[q].y;
+      x.z = (x.z + bias4.z) * sc + re[q].z; x.w = (x.w + bias4.w) * sc + re[q].w;
+      stream_store(cf, x);
+      v[q] = x;
+      s1[q] = (x.x + x.y) + (x.z + x.w);
+    }
+#pragma unroll
+    for (int o = TPRW / 2; o > 0; o >>= 1)
+#pragma unroll
+      for (int q = 0; q < NR; ++q) s1[q] += __shfl_xor(s1[q], o);
+    constexpr float invn = 1.0f / (4 * TPRW);
+    float s2[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const float mu = s1[q] * invn;
+      s1[q] = mu;
+      v[q].x -= mu; v[q].y -= mu; v[q].z -= mu; v[q].w -= mu;
+      s2[q] = (v[q].x * v[q].x + v[q].y * v[q].y) + (v[q].z * v[q].z + v[q].w * v[q].w);
+    }
+#pragma unroll
+    for (int o = TPRW / 2; o > 0; o >>= 1)
+#pragma unroll
+      for (int q = 0; q < NR; ++q) s2[q] += __shfl_xor(s2[q], o);
+    __bf16* yo = static_cast<__bf16*>(g.ln_out) + row0 * g.N + n;
+    const int tbase = g.ln_mod ? (int)(row0 % ((int64_t)g.ln_hw * g.ln_hw)) : 0;       // a row tile never crosses an image
+#pragma unroll
+    for (int q = 0; q < NR; ++q, yo += (int64_t)RPP * g.N) {
+      const float rs = 1.0f / sqrtf(s2[q] * invn + 1e-5f);
+      float4 o = make_float4(v[q].x * rs * gm.x + bt.x, v[q].y * rs * gm.y + bt.y, v[q].z * rs * gm.z + bt.z, v[q].w * rs * gm.w + bt.w);
+      if (g.ln_mod) {
+        const float4 mm = *reinterpret_cast<const float4*>(g.ln_mod + (int64_t)ln_window_pos(tbase + q * RPP, g.ln_hw, g.ln_shift) * g.N + n);
+        o.x += mm.x; o.y += mm.y; o.z += mm.z; o.w += mm.w;
+      }
+      stream_store(yo, make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w)));
+      if ((threadIdx.x % TPRW) == 0) { g.ln_mean[row0 + (int64_t)q * RPP] = s1[q]; g.ln_rstd[row0 + (int64_t)q * RPP] = rs; }
+    }
+    return;
+  }
   uint2 ga[NR];
   float4 re[NR];
   if constexpr (EPI == 2) {
@@ -233,7 +292,7 @@ __device__ __forceinline__ void epi_interior(const float* cs, const WmGemm& g, i
 // ------------------------------------------------------------------------------------------------------------------
 // bf16 x bf16 instances are held to 168 registers per lane (3 waves per SIMD = 3 workgroups per CU); they need 172 unconstrained
 template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int EPI>
-__global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 ? 3 : 2)) void gemm_nt_kernel(const WmGemm g, const bool vec_ok, const int tiles_n, const int tiles_m) {
+__global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 && EPI != 4 ? 3 : 2)) void gemm_nt_kernel(const WmGemm g, const bool vec_ok, const int tiles_n, const int tiles_m) {
   constexpr int BK = 64, BM = WM * TM * 32, BN = WN * TN * 32, LDA = BK + 8;
   constexpr int LDB = B_TR ? BN + 32 : BK + 8, BSZ = B_TR ? BK * LDB : BN * LDB;
   constexpr int NBUF = NT_NBUF;                              // LDS operand buffers (1: more workgroups per CU, one more barrier per k tile)
@@ -350,7 +409,7 @@ __global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 ? 3 : 2)) void ge
     const int mp = m0 + pass * PR;                            // first row of this pass
     if constexpr (EPI != 3) {
       if (full && mp + PR <= g.M) {                           // (the host picked EPI from the operands that are present)
-        epi_interior<EPI, PR / RPP, RPP, LDC>(Cs + (tid / TPRW) * LDC + 4 * c4, g, mp + tid / TPRW, n, bias4, g.rowscale ? sc_tile : 1.f);
+        epi_interior<EPI, PR / RPP, RPP, LDC, TPRW>(Cs + (tid / TPRW) * LDC + 4 * c4, g, mp + tid / TPRW, n, bias4, g.rowscale ? sc_tile : 1.f);
         continue;
       }
     }
@@ -611,6 +670,17 @@ int launch_nt(const WmGemm& g, hipStream_t st) {
   const bool vec_ok = al16(g.C) && !(g.ldc & 7) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && !(g.ldr & 3))) &&
                       (!g.gaux || (al16(g.gaux) && !(g.ldg & 7)));
   const bool sc_ok = !g.rowscale || (g.rows_per_scale % BM) == 0;
+  if (g.ln_out) {                                              // fused LayerNorm: whole rows in the tile, interior path only
+    constexpr int BN = WN * TN * 32;
+    if constexpr (BN <= 128 && !B_TR && !A_GELU && sizeof(AT) == 2) {
+      if (!(vec_ok && sc_ok) || g.c_bf16 || !g.res || g.gaux || g.N != BN || (g.M % BM) || !al16(g.ln_gamma) || !al16(g.ln_beta) ||
+          !al16(g.ln_out) || (g.ln_mod && (!al16(g.ln_mod) || g.ln_hw <= 0 || ((int64_t)g.ln_hw * g.ln_hw) % BM)))
+        return WM_EINVAL;
+      return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 4>(g, vec_ok, st);
+    } else {
+      return WM_EINVAL;
+    }
+  }
   if (vec_ok && sc_ok) {
     if (g.c_bf16 && !g.gaux && !g.res) return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 0>(g, vec_ok, st);
     if (!g.c_bf16 && g.res && !g.gaux) return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 1>(g, vec_ok, st);
@@ -624,6 +694,12 @@ template <typename AT, typename BT, bool B_TR, bool A_GELU>
 int dispatch_nt(const WmGemm& g, hipStream_t st) {
   const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
   const int64_t t12864 = (int64_t)((g.M + 127) / 128) * ((g.N + 63) / 64);
+  if (g.ln_out) {                                              // the tile must hold whole rows: width = N
+    if (g.N == 32) return launch_nt<AT, BT, B_TR, A_GELU, 4, 1, 2, 1>(g, st);
+    if (g.N == 64) return launch_nt<AT, BT, B_TR, A_GELU, 2, 2, 2, 1>(g, st);
+    if (g.N == 128) return launch_nt<AT, BT, B_TR, A_GELU, 2, 2, 2, 2>(g, st);
+    return WM_EINVAL;
+  }
   if (g.N <= 32) return launch_nt<AT, BT, B_TR, A_GELU, 4, 1, 2, 1>(g, st);          // 256 x 32
   // N = 192 (qkv at C = 64) leaves the second 128-wide column tile half empty: three full 64-wide tiles instead
   // (measured at B = 96: 301.9 -> 218.1 us at 1.57 M rows, 77.4 -> 55.6 us at 393 k rows)

@@ -332,7 +332,7 @@ int launch_nt_pp(const WmGemm& g, hipStream_t st) {
 
 // launchers for gemm_big.hip's dispatch (which has checked shapes and alignment)
 int wm_gemm_pp_nt_launch(const WmGemm& g, int epi, hipStream_t st) {
-  return epi == 0 ? launch_nt_pp<0>(g, st) : epi == 1 ? launch_nt_pp<1>(g, st) : launch_nt_pp<2>(g, st);
+  return epi == 0 ? launch_nt_pp<0>(g, st) : epi == 1 ? launch_nt_pp<1>(g, st) : epi == 2 ? launch_nt_pp<2>(g, st) : launch_nt_pp<4>(g, st);
 }
 int wm_gemm_pp_tn_launch(const WmGemm& g, int klen, int tiles_n, int tiles_m, int ksplit, float* part, hipStream_t st) {
   static bool attr = false;

@@ -217,9 +217,34 @@ class UformerAudio(nn.Module):
                 self._offsets[name] = off
                 off += (math.prod(shape) + 7) // 8 * 8
             self._seg_sizes.append(off - start)
+        # gradient-ready granules for the data-parallel exchange: a LeWin block or a convolution owns one contiguous arena run
+        # (its parameters are consecutive specs); runs tile the optimised part of the arena without gaps
+        self._owner_range, runs = {}, []
+        for name, shape, _ in seg_a + seg_b + seg_c:
+            owner = self._owner_of(name)
+            if not runs or runs[-1][0] != owner:
+                runs.append([owner, self._offsets[name]])
+        ends = [r[1] for r in runs[1:]] + [sum(self._seg_sizes[:3])]
+        for (owner, lo), hi in zip(runs, ends):
+            self._owner_range[owner] = (lo, hi)
         self._build_arena(torch.device("cpu"), init=True)
         self._anchor = None
         self._step_t = None
+        self._grad_ready = None
+
+    @staticmethod
+    def _owner_of(name):
+        parts = name.split(".")
+        if "blocks" in parts:
+            k = parts.index("blocks")
+            return ".".join(parts[:k + 2]) + "."
+        return ".".join(parts[:-1]) + "."
+
+    def segment_bounds(self):
+        """[lo, hi) arena element ranges of the three gradient segments in the order backward finishes them (extractor +
+        stft_layer, decoder + output_proj, encoder + payload autoencoder)."""
+        a, b, c = self._seg_sizes[:3]
+        return [(a + b, a + b + c), (a, a + b), (0, a)]
 
     # ---- parameter arena -------------------------------------------------------------------
     def _build_arena(self, device, init=False, flat=None):
@@ -429,30 +454,48 @@ class UformerAudio(nn.Module):
         ops.droppath_scales(sc, self._rates, n, B, rank_seed(self.seed), self._step_t)
         return sc
 
-    def _block_fwd(self, pre, x, B, C, hw, shift, s1, s2, mod):
+    def _block_fwd(self, pre, x, B, C, hw, shift, s1, s2, mod, ln1=None, next_ln=None):
+        """One LeWin block (model.py:937-1019).  In bf16 mode the two LayerNorms ride in the epilogue of the GEMM that produces
+        their input where a tile holds whole rows (C <= 128, C = 256 on the 256 x 256 tiles): norm2 behind the attention
+        projection, and the NEXT block's norm1 behind fc2 (``next_ln`` = (prefix, shift, modulator?) of that block; its result is
+        returned and handed to that block as ``ln1``).  Returns (x2, tape, next block's (xn1, mean1, rstd1) or None)."""
         P, dev, mode = self._views, x.device, self._mode()
         M, N = x.shape[0], hw * hw
         H, W = self._H, self._W
-        xn1, mean1, rstd1 = H(dev, M, C), _E(dev, M), _E(dev, M)
-        ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], P[pre + "modulator.weight"] if mod else None,
-                          xn1, mean1, rstd1, hw, shift)
+        half = self.compute_mode == "bf16"
+        if ln1 is None:
+            xn1, mean1, rstd1 = H(dev, M, C), _E(dev, M), _E(dev, M)
+            ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], P[pre + "modulator.weight"] if mod else None,
+                              xn1, mean1, rstd1, hw, shift)
+        else:
+            xn1, mean1, rstd1 = ln1
         qkv = H(dev, M, 3 * C)
         ops.linear_fwd(xn1, W(pre + "attn.qkv.w"), P[pre + "attn.qkv.b"], qkv, mode)
         o = H(dev, M, C)
-        lse = _E(dev, M, C // 32) if self.compute_mode == "bf16" else None
+        lse = _E(dev, M, C // 32) if half else None
         ops.winattn_fwd(qkv, P[pre + "attn.relative_position_bias_table"], o, B, hw, C, shift, mode, lse=lse)
         x1 = _E(dev, M, C)
-        ops.linear_fwd(o, W(pre + "attn.proj.weight"), P[pre + "attn.proj.bias"], x1, mode, res=x, rowscale=s1, rows_per_scale=N)
         xn2, mean2, rstd2 = H(dev, M, C), _E(dev, M), _E(dev, M)
-        ops.layernorm_fwd(x1, P[pre + "norm2.weight"], P[pre + "norm2.bias"], None, xn2, mean2, rstd2, hw, 0)
+        if half and ops.ln_fusable(M, C, C, mode):
+            ops.linear_fwd(o, W(pre + "attn.proj.weight"), P[pre + "attn.proj.bias"], x1, mode, res=x, rowscale=s1, rows_per_scale=N,
+                           ln=(P[pre + "norm2.weight"], P[pre + "norm2.bias"], None, xn2, mean2, rstd2, hw, 0))
+        else:
+            ops.linear_fwd(o, W(pre + "attn.proj.weight"), P[pre + "attn.proj.bias"], x1, mode, res=x, rowscale=s1, rows_per_scale=N)
+            ops.layernorm_fwd(x1, P[pre + "norm2.weight"], P[pre + "norm2.bias"], None, xn2, mean2, rstd2, hw, 0)
         h1 = H(dev, M, 4 * C)
         ops.linear_fwd(xn2, W(pre + "mlp.linear1.0.weight"), P[pre + "mlp.linear1.0.bias"], h1, mode)
         a2, h2 = H(dev, M, 4 * C), H(dev, M, 4 * C)       # h2 holds gelu'(dwconv output): all backward needs of it
         ops.dwconv_fwd(h1, P[pre + "mlp.dwconv.0.weight"], P[pre + "mlp.dwconv.0.bias"], None, B, hw, 4 * C, a2=a2, g2=h2)
         x2 = _E(dev, M, C)
+        ln, nxt = None, None
+        if next_ln is not None and half and ops.ln_fusable(M, C, 4 * C, mode):
+            npre, nshift, nmod = next_ln
+            nxt = (H(dev, M, C), _E(dev, M), _E(dev, M))
+            ln = (P[npre + "norm1.weight"], P[npre + "norm1.bias"], P[npre + "modulator.weight"] if nmod else None,
+                  nxt[0], nxt[1], nxt[2], hw, nshift)
         ops.linear_fwd(a2, W(pre + "mlp.linear2.0.weight"), P[pre + "mlp.linear2.0.bias"], x2, mode, res=x1,
-                       rowscale=s2, rows_per_scale=N)
-        return x2, (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2, lse)
+                       rowscale=s2, rows_per_scale=N, ln=ln)
+        return x2, (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, a2, lse), nxt
 
     def _block_bwd(self, sv, dy, dyh=None, consumer_scale=None):
         """Returns (dx, dxh): dxh is a bf16 copy of dx in bf16 mode (the next block's GEMM operand), else None.
@@ -509,6 +552,8 @@ class UformerAudio(nn.Module):
                           scratch=sl1, defer=jobs.take(2), dx_bf16=dxh, copy_scale=consumer_scale if half else None,
                           rows_per_scale=N)
         ops.reduce_jobs(jobs)
+        if self._grad_ready is not None:
+            self._grad_ready(*self._owner_range[pre])              # this block's gradients are final
         return dx, dxh
 
     @staticmethod
@@ -541,6 +586,8 @@ class UformerAudio(nn.Module):
         dw2 = _Z(dev, 2 * C, 16 * C)
         ops.linear_bwd_weight(dyg, cols, dw2, G[pre + "bias"], mode, scratch=self._gemm_scratch(dev))
         ops.strided3(dw2, G[pre + "weight"], (2 * C, 16, C), (16 * C, C, 1), (16 * C, 1, 16), atomic=True)
+        if self._grad_ready is not None:
+            self._grad_ready(*self._owner_range[pre])
         return dx
 
     def _up_fwd(self, pre, x, B, hw, Cin, Co, skip):
@@ -570,6 +617,8 @@ class UformerAudio(nn.Module):
         ops.linear_bwd_weight(dy4, x, dwr, db4, mode, scratch=self._gemm_scratch(dev))
         ops.strided3(dwr, G[pre + "weight"], (4, Co, Cin), (Co * Cin, Cin, 1), (1, 4, 4 * Co), atomic=True)
         ops.strided3(db4, G[pre + "bias"], (1, 4, Co), (0, Co, 1), (0, 0, 1), atomic=True)
+        if self._grad_ready is not None:
+            self._grad_ready(*self._owner_range[pre])
         return dx, dskip
 
     def _trunk_fwd(self, pre, img, B, scales, slot0, extractor):
@@ -588,12 +637,14 @@ class UformerAudio(nn.Module):
         bi = 0
         for i in range(5):
             C, hw = self.arch.embed << i, self.arch.img >> i
+            bname = (lambda jj: f"{pre}encoderlayer_{i}.blocks.{jj}." if i < 4 else f"{pre}conv.blocks.{jj}.")
+            ln1 = None
             for j in range(self.arch.depths[i]):
                 (_, _, _, _, _, shift, rate) = blocks[bi]
-                name = f"{pre}encoderlayer_{i}.blocks.{j}." if i < 4 else f"{pre}conv.blocks.{j}."
                 s1 = scales[slot] if (scales is not None and rate > 0) else None
                 s2 = scales[slot + 1] if (scales is not None and rate > 0) else None
-                y, sv = self._block_fwd(name, y, B, C, hw, shift, s1, s2, False)
+                nxt = (bname(j + 1), blocks[bi + 1][5], False) if j + 1 < self.arch.depths[i] else None
+                y, sv, ln1 = self._block_fwd(bname(j), y, B, C, hw, shift, s1, s2, False, ln1=ln1, next_ln=nxt)
                 tape.append(("block", sv))
                 slot += 2
                 bi += 1
@@ -720,11 +771,15 @@ class UformerAudio(nn.Module):
             C, hw = self.arch.embed << (4 - i), self.arch.img >> (3 - i)
             y, sv = self._up_fwd(f"decoder.upsample_{i}.deconv.0.", y, B, hw // 2, cin[i], C // 2, feats[3 - i])
             dtape.append(("up", sv, i))
+            ln1 = None
             for j in range(self.arch.depths[5 + i]):
                 (_, _, _, _, _, shift, rate) = dblocks[bi]
                 s1 = scales[slot] if (scales is not None and rate > 0) else None
                 s2 = scales[slot + 1] if (scales is not None and rate > 0) else None
-                y, sv = self._block_fwd(f"decoder.decoderlayer_{i}.blocks.{j}.", y, B, C, hw, shift, s1, s2, self.arch.modulator)
+                nxt = (f"decoder.decoderlayer_{i}.blocks.{j + 1}.", dblocks[bi + 1][5], self.arch.modulator) \
+                    if j + 1 < self.arch.depths[5 + i] else None
+                y, sv, ln1 = self._block_fwd(f"decoder.decoderlayer_{i}.blocks.{j}.", y, B, C, hw, shift, s1, s2,
+                                             self.arch.modulator, ln1=ln1, next_ln=nxt)
                 dtape.append(("block", sv))
                 slot += 2
                 bi += 1
@@ -765,8 +820,11 @@ class UformerAudio(nn.Module):
         S["B"], S["extract_from"], S["feats"] = B, extract_from, feats
         return (stft_new, noise, wm_pred, wm), S
 
-    def _backward_impl(self, S, d_stft_new, d_noise, d_wm_pred, d_wm, after_segment=None):
+    def _backward_impl(self, S, d_stft_new, d_noise, d_wm_pred, d_wm, after_segment=None, grad_ready=None):
+        """after_segment(i): segment i of segment_bounds() is complete; grad_ready(lo, hi): the arena run [lo, hi) (a LeWin block
+        or a down / up-sampling convolution) is final — the data-parallel exchange starts on it while backward goes on."""
         P, G = self._views, self._gviews
+        self._grad_ready = grad_ready
         B = S["B"]
         dev = self._flat.device
 
@@ -830,6 +888,7 @@ class UformerAudio(nn.Module):
         d_in, x, tok = S["inproj"]
         ops.conv_bwd(d_in, x, P["input_proj.proj.0.weight"], tok, dtok0, None, G["input_proj.proj.0.weight"], G["input_proj.proj.0.bias"])
         self._ae_encode_bwd(S["ae_enc"], df0, B)
+        self._grad_ready = None
         if after_segment is not None:
             after_segment(2)
 

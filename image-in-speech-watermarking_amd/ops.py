@@ -30,20 +30,36 @@ def _bf(t):
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=1, b_kc=1, a_op=0, b_op=0, bias=None, res=None, ldr=0,
          rowscale=None, rows_per_scale=0, kscale=None, k_per_scale=0, gaux=None, ldg=0, b_ones=False, C2=None,
-         atomic_out=False, ksplit=0, mode=MODE_FP32, gaux_raw=False, scratch=None, defer=None):
+         atomic_out=False, ksplit=0, mode=MODE_FP32, gaux_raw=False, scratch=None, defer=None, ln=None):
+    lnf = (None, None, None, None, None, None, 0, 0)
+    if ln is not None:
+        gamma, beta, mod, out, mean, rstd, hw, shift = ln
+        if out.dtype != torch.bfloat16:
+            raise ValueError("fused LayerNorm output is bf16 (bf16 mode only)")
+        lnf = (ptr(gamma), ptr(beta), ptr(mod), ptr(out), ptr(mean), ptr(rstd), int(hw), int(shift))
     g = WmGemm(ptr(A), ptr(B), ptr(Cout), M, N, K, lda, ldb, ldc, a_kc, b_kc, a_op, b_op, ptr(bias), ptr(res), ldr,
                ptr(rowscale), rows_per_scale, ptr(kscale), k_per_scale, ptr(gaux), ldg, int(b_ones), ptr(C2),
                int(atomic_out), ksplit, mode, _bf(A), _bf(B), _bf(Cout), _bf(gaux), int(gaux_raw),
-               ptr(scratch), scratch.numel() if scratch is not None else 0, defer)
+               ptr(scratch), scratch.numel() if scratch is not None else 0, defer, *lnf)
     check(lib.wm_gemm(C.byref(g), _stream()), f"wm_gemm(M={M},N={N},K={K})")
 
 
-def linear_fwd(x, w, bias, out, mode, a_op=0, res=None, rowscale=None, rows_per_scale=0):
-    """out[M,N] = (op(x)[M,K] @ w[N,K]^T + bias) * rowscale + res"""
+def ln_fusable(M, N, K, mode, a_bf16=True):
+    """Can linear_fwd(..., ln=...) produce the LayerNorm of its output rows in the same launch?  (WM_NO_LN_FUSE=1: never — the
+    A/B switch of the benchmarks.)"""
+    import os
+    if os.environ.get("WM_NO_LN_FUSE") == "1":
+        return False
+    return bool(lib.wm_gemm_ln_fusable(M, N, K, mode, int(a_bf16)))
+
+
+def linear_fwd(x, w, bias, out, mode, a_op=0, res=None, rowscale=None, rows_per_scale=0, ln=None):
+    """out[M,N] = (op(x)[M,K] @ w[N,K]^T + bias) * rowscale + res;  ln = (gamma, beta, modulator or None, y_bf16, mean, rstd, hw,
+    shift): y = LayerNorm(out rows) * gamma + beta (+ modulator[window position]) written by the same launch."""
     M, K = x.shape
     N = w.shape[0]
     gemm(x, w, out, M, N, K, K, K, N, 1, 1, a_op=a_op, bias=bias, res=res, ldr=N, rowscale=rowscale,
-         rows_per_scale=rows_per_scale, mode=mode)
+         rows_per_scale=rows_per_scale, mode=mode, ln=ln)
 
 
 def linear_bwd_input(dy, w, dx, mode, rowscale=None, rows_per_scale=0, gaux=None, gaux_raw=False, wT=None):

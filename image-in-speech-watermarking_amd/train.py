@@ -61,22 +61,76 @@ class FusedAdamW:
 
 
 class GradSync:
-    """Data-parallel gradient exchange over the flat arena: three contiguous slices, each all-reduced (SUM; the
-    1/world mean is folded into AdamW's grad scale) as soon as backward has finished it.  On a GPU the collective
-    runs on a side stream (RCCL over xGMI) so it overlaps the remaining backward; with gloo/CPU tensors (tests)
-    it is issued synchronously.  Reference: none — the reference is single-device."""
+    """Data-parallel gradient exchange over the flat gradient arena (reference: none — the reference is single-device,
+    SURVEY 2 / 8e).  Backward reports every finished arena run (a LeWin block, a down / up-sampling convolution: `ready`);
+    adjacent runs are merged and a merged run is all-reduced (SUM; the 1/world mean is folded into AdamW's grad scale) as soon
+    as it reaches ``bucket_bytes`` (~25 MB: SURVEY 8e), on a side stream over RCCL / xGMI, so that the transfers overlap the
+    remaining backward and only the small remainder of the last segment is exposed in front of AdamW.  ``segment_done`` flushes
+    what is left of a segment (its convolutions, a partial bucket).  With gloo / CPU tensors (tests) the collectives are issued
+    synchronously.  The merge logic is deterministic in the call sequence, so a planning pass (``plan=True``: nothing is sent,
+    `on_launch` is called where a collective would start) tells TrainStep where to cut its captured graphs."""
 
-    def __init__(self, net, process_group=None):
+    def __init__(self, net, process_group=None, bucket_bytes=25 << 20):
         self.net, self.pg = net, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.cuda = net._flat.is_cuda
         self._comm = torch.cuda.Stream(device=net._flat.device) if (self.cuda and self.world > 1) else None
-        self.timing = None                                      # bench.py: list of (bucket, start event, stop event)
+        self.bucket_elems = max(int(bucket_bytes) // 4, 1)
+        self.timing = None                                      # bench.py: list of (lo, hi, start event, stop event)
+        self.force = False                                      # tests / rehearsals: run the bucket logic on one rank too
+        self.reset()
 
-    def after_segment(self, idx):
+    # -- bookkeeping ---------------------------------------------------------------------------------
+    def reset(self):
+        self._pending = []                                      # sorted, disjoint [lo, hi) runs that are final but not sent
+        self._sent = []                                         # runs already handed to a collective in this step
+        self._seg = 0
+
+    def _active(self):
+        return self.world > 1 or self.force
+
+    def ready(self, lo, hi, plan=False, on_launch=None):
+        if not self._active() or hi <= lo:
+            return
+        runs = sorted(self._pending + [(lo, hi)])
+        merged = [runs[0]]
+        for a, b in runs[1:]:
+            if a <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+            else:
+                merged.append((a, b))
+        self._pending = []
+        for a, b in merged:
+            if b - a >= self.bucket_elems:
+                self._launch(a, b, plan, on_launch)
+            else:
+                self._pending.append((a, b))
+
+    def segment_done(self, idx, plan=False, on_launch=None):
+        """Everything of segment idx that has not been sent yet goes out now (in as few contiguous pieces as possible)."""
+        if not self._active():
+            return
+        lo, hi = self.net.segment_bounds()[idx]
+        sent = sorted((a, b) for a, b in self._sent if a < hi and b > lo)
+        self._pending = [(a, b) for a, b in self._pending if not (a < hi and b > lo)]
+        cur = lo
+        for a, b in sent + [(hi, hi)]:
+            if a > cur:
+                self._launch(cur, a, plan, on_launch)
+            cur = max(cur, b)
+
+    def _launch(self, lo, hi, plan, on_launch):
+        self._sent.append((lo, hi))
+        if on_launch is not None:
+            on_launch(lo, hi)
+        if not plan:
+            self.all_reduce(lo, hi)
+
+    # -- the collective ------------------------------------------------------------------------------
+    def all_reduce(self, lo, hi):
+        bucket = self.net._flat_grad[lo:hi]
         if self.world == 1:
             return
-        bucket = self.net.grad_buckets()[idx]
         if self._comm is None:
             dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg)
             return
@@ -88,11 +142,16 @@ class GradSync:
             dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg)
             if self.timing is not None:
                 e.record()
-                self.timing.append((idx, s, e))
+                self.timing.append((lo, hi, s, e))
+
+    # the three-segment interface of round 1 / 2 (segment i complete): now a flush
+    def after_segment(self, idx):
+        self.segment_done(idx)
 
     def finish(self):
         if self._comm is not None:
             torch.cuda.current_stream().wait_stream(self._comm)
+        self.reset()
 
 
 class TrainStep:
@@ -126,10 +185,11 @@ class TrainStep:
         self.outputs = None
 
     # -- the launch sequence (no host syncs, no python-side data dependence) ------------------------
-    def _launch(self, after_segment=None, before_optimizer=None):
+    def _launch(self, after_segment=None, before_optimizer=None, grad_ready=None):
         net, B = self.net, self.B
-        if after_segment is None and self.world > 1:
-            after_segment, before_optimizer = self.sync.after_segment, self.sync.finish
+        if after_segment is None and self.sync._active():
+            after_segment, before_optimizer, grad_ready = self.sync.segment_done, self.sync.finish, self.sync.ready
+            self.sync.reset()
         ops.zero_(net._flat_grad)
         ops.step_inc(net._step_t)                               # advances the DropPath / AWGN Philox streams
         outs, S = net._forward_impl(self.x, self.msg, train=net.training, keep_scales=None, attack=self.attack,
@@ -137,7 +197,7 @@ class TrainStep:
         d = [torch.empty_like(o) for o in outs]
         ops.loss_fwd_bwd(outs[0], self.x, outs[1], outs[2], outs[3], self.msg, self.losses, d[0], d[1], d[2], d[3], B,
                          self._scratch)
-        net._backward_impl(S, d[0], d[1], d[2], d[3], after_segment=after_segment)
+        net._backward_impl(S, d[0], d[1], d[2], d[3], after_segment=after_segment, grad_ready=grad_ready)
         if before_optimizer is not None:
             before_optimizer()
         self.opt.launch()
@@ -197,40 +257,52 @@ class TrainStep:
         torch.cuda.empty_cache()
 
     def _capture_segments(self):
-        """Capture the launch sequence as graphs cut where backward has finished a gradient bucket.  Nothing executes
-        during the pass and no collective is recorded: ``_replay_segments`` issues the all-reduce of bucket i after
-        graph i.  All graphs allocate from one pool, replayed in capture order, so tensors that live across a cut keep
-        their addresses."""
-        graphs, cuts = [torch.cuda.CUDAGraph()], []
+        """Capture the launch sequence as graphs cut wherever the gradient exchange starts collectives (a ~25 MB bucket is
+        complete, or a segment ends).  Nothing executes during the pass and no collective is recorded: GradSync runs its bucket
+        logic in planning mode and reports the launches; ``_replay_segments`` issues them after the graph they follow.  All
+        graphs allocate from one pool, replayed in capture order, so tensors that live across a cut keep their addresses."""
+        graphs, launches = [torch.cuda.CUDAGraph()], []
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        sync = self.sync
+        force0, sync.force = sync.force, True                      # plan the cuts on one rank too (``segmented`` rehearsals)
 
-        def cut(idx):
-            graphs[-1].capture_end()
-            cuts.append(idx)
-            graphs.append(torch.cuda.CUDAGraph())
-            graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
+        def planned(call, *args):
+            sends = []
+            call(*args, plan=True, on_launch=lambda lo, hi: sends.append((lo, hi)))
+            if sends:                                              # the collectives of this point follow the graph that ends here
+                graphs[-1].capture_end()
+                launches.append(sends)
+                graphs.append(torch.cuda.CUDAGraph())
+                graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
 
-        with torch.cuda.stream(side):
-            graphs[0].capture_begin(capture_error_mode="thread_local")
-            try:
-                self._launch(after_segment=cut, before_optimizer=lambda: None)
-            except BaseException:
+        sync.reset()
+        try:
+            with torch.cuda.stream(side):
+                graphs[0].capture_begin(capture_error_mode="thread_local")
                 try:
-                    graphs[-1].capture_end()                    # leave capture mode before reporting
-                except RuntimeError:
-                    pass
-                raise
-            graphs[-1].capture_end()
+                    self._launch(after_segment=lambda idx: planned(sync.segment_done, idx), before_optimizer=lambda: None,
+                                 grad_ready=lambda lo, hi: planned(sync.ready, lo, hi))
+                except BaseException:
+                    try:
+                        graphs[-1].capture_end()                    # leave capture mode before reporting
+                    except RuntimeError:
+                        pass
+                    raise
+                graphs[-1].capture_end()
+        finally:
+            sync.force = force0
+            sync.reset()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._segments = (graphs, cuts)
+        launches.append([])                                        # the last graph (AdamW) is followed by nothing
+        self._segments = (graphs, launches)
 
     def _replay_segments(self):
-        graphs, cuts = self._segments
-        for i, g in enumerate(graphs):
+        graphs, launches = self._segments
+        for i, (g, sends) in enumerate(zip(graphs, launches)):
+            if i == len(graphs) - 1:
+                self.sync.finish()                              # the last graph (AdamW) waits for the collectives
             g.replay()
-            if i < len(cuts):
-                self.sync.after_segment(cuts[i])
-                if i == len(cuts) - 1:
-                    self.sync.finish()                          # the last graph (tail of backward + AdamW) waits for the collectives
+            for lo, hi in sends:
+                self.sync.all_reduce(lo, hi)

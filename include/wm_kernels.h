@@ -65,7 +65,16 @@ typedef struct WmGemm {
   float* scratch;            /* optional device workspace for split-K partial tiles (weight gradients, mode 1); NULL =  */
   int64_t scratch_floats;    /* fp32 atomics into C.  wm_gemm_scratch_floats() is always enough; contents irrelevant    */
   WmReduceJob* defer;        /* optional HOST pointer to 1 entry: the split-K reduction is described there, not launched */
+  /* Optional fused LayerNorm of the OUTPUT rows (mode 1, fp32 C with residual, N in {32, 64, 128, 256}: the tile holds whole
+   * rows): ln_out[M,N] (bf16) = LayerNorm(C row) * ln_gamma + ln_beta (+ ln_mod[window position of the row][n], the decoder's
+   * modulator, reference model.py:996-997), ln_mean / ln_rstd [M] for the backward.  This is norm2 behind the attention
+   * projection, or the NEXT block's norm1 behind fc2 (model.py:1016-1017 -> :982).  wm_gemm_ln_fusable() says whether a launch
+   * qualifies; otherwise wm_gemm returns WM_EINVAL when ln_out is set.                                                    */
+  const float* ln_gamma; const float* ln_beta; const float* ln_mod;
+  void* ln_out; float* ln_mean; float* ln_rstd;
+  int32_t ln_hw, ln_shift;
 } WmGemm;
+int32_t wm_gemm_ln_fusable(int32_t M, int32_t N, int32_t K, int32_t mode, int32_t a_bf16);
 int64_t wm_gemm_scratch_floats(void);
 int wm_gemm(const WmGemm* g, void* stream);
 

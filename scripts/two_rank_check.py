@@ -35,7 +35,7 @@ def main():
     for _ in range(6):
         step.step(x, msg)
     torch.cuda.synchronize()
-    assert step.use_graph and step._segments is not None and len(step._segments[0]) == 4, "segmented capture not in use"
+    assert step.use_graph and step._segments is not None and len(step._segments[0]) >= 10, "segmented capture not in use"
     n = m.optimized_numel
     mine = m._flat[:n].clone()
     both = [torch.empty_like(mine) for _ in range(world)]
@@ -60,7 +60,7 @@ def main():
             solo.step(x, msg)
         torch.cuda.synchronize()
         d = (m1._flat[:n] - both[0]).abs().max().item()
-        print(f"two ranks in sync after 6 steps (4 graphs per step); |solo - dp| max {d:.3e}; "
+        print(f"two ranks in sync after 6 steps ({len(step._segments[0])} graphs per step); |solo - dp| max {d:.3e}; "
               f"{1e3 * dt:.1f} ms/step with gloo on a shared GPU; losses {step.losses[:5].tolist()}")
         assert d > 1e-6
     dist.barrier()

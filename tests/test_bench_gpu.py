@@ -28,15 +28,41 @@ def test_gpus_flag_without_devices_fails_loudly():
 @pytest.mark.gpu
 def test_gpus_flag_starts_the_ranks_itself():
     """`python bench.py --gpus 2 --rehearse-one-gpu`: two rank processes share GPU 0 over gloo (RCCL refuses two ranks per
-    device), the chain of four graphs with the all-reduces between them runs, the line says n_gpus 2."""
+    device), the chain of graphs with the ~25 MB bucket all-reduces between them runs, the line says n_gpus 2."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu"] + QUICK,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["config"]["global_tiles"] == 4 and line["config"]["graph_segments"] == 4
+    assert line["n_gpus"] == 2 and line["config"]["global_tiles"] == 4 and line["config"]["graph_segments"] >= 10
     assert line["config"]["baseline_config"] == 3 and "full audio_attack stack" in line["config"]["workload"]
-    assert [b["bucket"] for b in line["allreduce"]] == ["extractor", "decoder", "encoder"]
+    ar = line["allreduce"]
+    assert len(ar["buckets_in_launch_order"]) >= 10 and abs(sum(b["MB"] for b in ar["buckets_in_launch_order"]) - 274.9) < 1.0
+    assert ar["exposed_tail_MB"] < 20 and all(b["ms"] > 0 for b in ar["buckets_in_launch_order"])
     assert "roofline" not in line and "cpu_baseline" not in line
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_of_config5_clips():
+    """`--gpus 2 --clip-seconds 10` (config 5's shape: 10-tile clips, 64 x 64 payload as quadrants) over the N-rank path."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--clip-seconds", "10",
+                        "--steps", "2", "--warmup", "1", "--batch", "10", "--no-cpu-baseline", "--no-kernel-timing"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["baseline_config"] == 5 and line["config"]["global_tiles"] == 20
+    assert "10 s 16 kHz clips" in line["config"]["workload"] and line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_launcher_stops_when_a_rank_fails():
+    """A rank that dies at start-up (here: --batch 7 with --clip-seconds 10 is rejected by every rank) ends the launcher with that
+    rank's message on stderr instead of leaving the others in a collective until the distributed timeout."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--clip-seconds", "10",
+                        "--batch", "7", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "multiple of 10" in r.stderr and time.time() - t0 < 300
 
 
 @pytest.mark.gpu

@@ -102,14 +102,32 @@ g = torch.Generator().manual_seed(100 + rank)
 net._flat_grad.copy_(torch.randn(net._flat_grad.numel(), generator=g))
 mine = net._flat_grad.clone()
 sync = wm.GradSync(net)
-order = []
-for idx in (0, 1, 2):                      # the order backward finishes the slices
-    sync.after_segment(idx); order.append(idx)
+sent = []
+orig = sync.all_reduce
+sync.all_reduce = lambda lo, hi: (sent.append((lo, hi)), orig(lo, hi))
+a = net.arch
+def trunk(pre):                            # the order backward finishes a trunk's blocks and down-sampling convolutions
+    out = []
+    for i in range(4, -1, -1):
+        out += [(f"{pre}encoderlayer_{i}.blocks.{j}." if i < 4 else f"{pre}conv.blocks.{j}.") for j in range(a.depths[i] - 1, -1, -1)]
+        if i > 0:
+            out.append(f"{pre}dowsample_{i - 1}.conv.0.")
+    return out
+dec = []
+for i in range(3, -1, -1):
+    dec += [f"decoder.decoderlayer_{i}.blocks.{j}." for j in range(a.depths[5 + i] - 1, -1, -1)] + [f"decoder.upsample_{i}.deconv.0."]
+for idx, owners in enumerate((trunk("decoder_wm."), dec, trunk("encoder."))):
+    for o in owners:
+        sync.ready(*net._owner_range[o])
+    sync.segment_done(idx)
 sync.finish()
 other = torch.randn(net._flat_grad.numel(), generator=torch.Generator().manual_seed(100 + (1 - rank)))
 n = net.optimized_numel
-assert torch.allclose(net._flat_grad[:n], (mine + other)[:n]), "all-reduce(sum) over the three buckets"
+assert torch.allclose(net._flat_grad[:n], (mine + other)[:n]), "every element of the optimised arena is all-reduced exactly once"
 assert torch.equal(net._flat_grad[n:], mine[n:]), "the unused tail is never exchanged"
+sizes = [(hi - lo) * 4 / 2 ** 20 for lo, hi in sent]
+assert len(sent) >= 10 and max(sizes) < 45, sizes                      # ~25 MB buckets, not three 69 / 136 / 69 MB slices
+assert sum(sizes[-2:]) < 20, sizes                                     # what is exposed in front of AdamW
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
