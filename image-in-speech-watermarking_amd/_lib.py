@@ -56,6 +56,7 @@ _SIGS = {
     "wm_gemm_scratch_floats": [],
     "wm_gemm": [C.POINTER(WmGemm), c_f],
     "wm_gemm_ln_fusable": [c_i32, c_i32, c_i32, c_i32, c_i32],
+    "wm_last_gemm_family": [],
     "wm_layernorm_fwd": [c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f],
     "wm_layernorm_bwd_scratch_floats": [c_i32],
     "wm_reduce_jobs": [C.POINTER(WmReduceJob), c_i32, c_f],

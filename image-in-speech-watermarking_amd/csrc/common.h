@@ -9,6 +9,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
+// which GEMM kernel family the last wm_gemm call of this host thread launched (profiling only: wm_last_gemm_family())
+enum { WM_FAM_GENERIC = 0, WM_FAM_NT = 1, WM_FAM_TN = 2, WM_FAM_NT_PP = 3, WM_FAM_TN_PP = 4, WM_FAM_NT_BIG = 5, WM_FAM_TN_BIG = 6 };
+extern thread_local int wm_gemm_family_tls;
+
 #define WM_OK 0
 #define WM_EINVAL 22
 

@@ -571,10 +571,13 @@ int dispatch(const WmGemm& g, int ksplit, hipStream_t st) {
 }  // namespace
 
 int wm_gemm_fast_bf16(const WmGemm& g, hipStream_t st);   // gemm_fast.hip: branch-free bf16 kernels, -1 = not applicable
+int wm_gemm_fast_split(const WmGemm& g, hipStream_t st);  // ... their split-precision instances (mode 2), -1 = not applicable
 int wm_gemm_big_bf16(const WmGemm& g, hipStream_t st);    // gemm_big.hip: 256 x 256 tiles for the compute-side shapes, -1 = not applicable
 int wm_gemm_big_tn_bf16(const WmGemm& g, hipStream_t st); // ... its weight-gradient form
 
-extern "C" int wm_abi_version(void) { return 4; }
+thread_local int wm_gemm_family_tls = WM_FAM_GENERIC;
+extern "C" int32_t wm_last_gemm_family(void) { return wm_gemm_family_tls; }
+extern "C" int wm_abi_version(void) { return 5; }
 // split-K slices of one weight-gradient launch: the 128 x 128 kernel writes up to ~384 tiles, the 256 x 256 kernel one tile
 // per CU (256 x 65536 floats = 67 MB)
 extern "C" int64_t wm_gemm_scratch_floats(void) { return 256LL * 256 * 256 + 1024 * 1024; }
@@ -602,16 +605,22 @@ extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
   if (g.b_kc && (g.K & bmask)) return WM_EINVAL;
   if (g.ksplit > 1 && !g.atomic_out) return WM_EINVAL;
   if (g.atomic_out && g.c_bf16) return WM_EINVAL;
-  if (g.mode == 0 && (g.a_bf16 || g.b_bf16)) return WM_EINVAL;       // parity mode keeps fp32 storage end to end
+  if ((g.mode == 0 || g.mode == 2) && (g.a_bf16 || g.b_bf16 || g.c_bf16)) return WM_EINVAL;   // parity modes keep fp32 storage end to end
   if (g.b_ones && !g.C2) return WM_EINVAL;
   if (g.kscale && (g.k_per_scale <= 0 || (g.k_per_scale & 3))) return WM_EINVAL;
   if (g.rowscale && g.rows_per_scale <= 0) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  wm_gemm_family_tls = WM_FAM_GENERIC;
   if (g.ln_out) {                                              // fused LayerNorm: only the kernels that hold whole rows
     if (g.mode != 1 || !g.ln_gamma || !g.ln_beta || !g.ln_mean || !g.ln_rstd || !wm_gemm_ln_fusable(g.M, g.N, g.K, g.mode, g.a_bf16))
       return WM_EINVAL;
     int rc = g.N == 256 ? wm_gemm_big_bf16(g, st) : wm_gemm_fast_bf16(g, st);
     return rc >= 0 ? rc : WM_EINVAL;
+  }
+  if (g.mode == 2) {                                           // split precision; shapes the fast kernels decline run exactly
+    const int rc = wm_gemm_fast_split(g, st);
+    if (rc >= 0) return rc;
+    return dispatch<float, float, float, false, 32>(g, g.ksplit, st);
   }
   if (g.mode == 0) return dispatch<float, float, float, false, 32>(g, g.ksplit, st);
   if (g.mode == 1) {

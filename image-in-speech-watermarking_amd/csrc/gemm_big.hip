@@ -283,6 +283,7 @@ int launch_nt_big(const WmGemm& g, hipStream_t st) {
     attr = true;
   }
   const int tiles_n = g.N / BN, tiles_m = (g.M + BM - 1) / BM;
+  wm_gemm_family_tls = WM_FAM_NT_BIG;
   hipLaunchKernelGGL((gemm_nt_big_kernel<EPI>), dim3(8 * ((tiles_m + 7) / 8) * tiles_n), dim3(512), SMEM_B, st, g, tiles_n, tiles_m);
   WM_CHECK_LAUNCH();
   return WM_OK;
@@ -366,6 +367,7 @@ int wm_gemm_big_tn_bf16(const WmGemm& g, hipStream_t st) {
     const int rc = wm_gemm_pp_tn_launch(g, klen, tiles_n, tiles_m, ksplit, part, st);
     if (rc) return rc;
   } else {
+    wm_gemm_family_tls = WM_FAM_TN_BIG;
     hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(8 * ((ksplit + 7) / 8) * tiles), dim3(512), SMEM_B, st, g, klen, tiles_n, tiles_m, ksplit, part);
     WM_CHECK_LAUNCH();
   }

@@ -68,6 +68,18 @@ template <> struct Chunk<float> {
     if (GELU) { x.x = gelu_f(x.x); x.y = gelu_f(x.y); x.z = gelu_f(x.z); x.w = gelu_f(x.w); }
     *reinterpret_cast<uint2*>(s) = make_uint2(pack_bf2(x.x * sc, x.y * sc), pack_bf2(x.z * sc, x.w * sc));
   }
+  // split precision (compute_mode "split"): x = hi + lo with hi = bf16(x), lo = bf16(x - hi); the two images lie lo_off apart
+  __device__ __forceinline__ void st_split(__bf16* s, int lo_off, float sc) const {
+    const float e[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      hi[u] = (__bf16)e[u];
+      lo[u] = (__bf16)(e[u] - (float)hi[u]);
+    }
+    *reinterpret_cast<bf16x4*>(s) = hi;
+    *reinterpret_cast<bf16x4*>(s + lo_off) = lo;
+  }
 };
 
 // Operand staging.  The k loop of both kernels spent more cycles issuing address arithmetic, bounds clamps and
@@ -78,8 +90,9 @@ template <> struct Chunk<float> {
 // (not even to zero it): that would make the compiler wait for the data first, i.e. no overlap.
 
 // [R rows][BK] tile of a K-contiguous operand -> LDS [R][BK + 8]
-template <typename ST, int R, int BK, bool GELU> struct KcStage {
+template <typename ST, int R, int BK, bool GELU, bool SPLIT = false> struct KcStage {
   static constexpr int E = Chunk<ST>::E, CPR = BK / E, RPP = 256 / CPR, NP = R / RPP, LD = BK + 8;
+  static constexpr int LO = R * LD;                          // SPLIT: offset of the low-part image (elements)
   static_assert(R % RPP == 0, "tile rows must be a multiple of the rows covered per pass");
   const ST* ptr[NP];                                         // this thread's chunk of the NEXT tile to load
   Chunk<ST> c[NP];
@@ -110,7 +123,8 @@ template <typename ST, int R, int BK, bool GELU> struct KcStage {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       if (edge) c[q].zero_if(!((rowok >> q) & 1));
-      c[q].template st<GELU>(s + soff + RPP * q * LD, 1.f, false);
+      if constexpr (SPLIT) c[q].st_split(s + soff + RPP * q * LD, LO, 1.f);
+      else c[q].template st<GELU>(s + soff + RPP * q * LD, 1.f, false);
     }
   }
   __device__ __forceinline__ void store_tail(__bf16* s, int k0, int kend) {
@@ -118,14 +132,16 @@ template <typename ST, int R, int BK, bool GELU> struct KcStage {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       c[q].zero_if(!kok || !((rowok >> q) & 1));
-      c[q].template st<GELU>(s + soff + RPP * q * LD, 1.f, false);
+      if constexpr (SPLIT) c[q].st_split(s + soff + RPP * q * LD, LO, 1.f);
+      else c[q].template st<GELU>(s + soff + RPP * q * LD, 1.f, false);
     }
   }
 };
 
 // [KT k-rows][R columns] tile of a row-contiguous operand -> LDS [KT][R + 32] (as it lies)
-template <typename ST, int R, int KT, bool GELU> struct TrStage {
+template <typename ST, int R, int KT, bool GELU, bool SPLIT = false> struct TrStage {
   static constexpr int E = Chunk<ST>::E, CPR = R / E, NCH = KT * CPR, NP = NCH / 256, RPQ = 256 / CPR, LD = R + 32;
+  static constexpr int LO = KT * LD;                         // SPLIT: offset of the low-part image (elements)
   static_assert(NCH % 256 == 0 && 256 % CPR == 0, "tile must be a multiple of 256 chunks");
   const ST* ptr[NP];                                         // this thread's chunk (row kr + RPQ q, fixed column) of the next tile
   Chunk<ST> c[NP];
@@ -161,14 +177,16 @@ template <typename ST, int R, int KT, bool GELU> struct TrStage {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       if (edge) c[q].zero_if(!colok);
-      c[q].template st<GELU>(s + soff + RPQ * q * LD, sc, scaled);
+      if constexpr (SPLIT) c[q].st_split(s + soff + RPQ * q * LD, LO, sc);
+      else c[q].template st<GELU>(s + soff + RPQ * q * LD, sc, scaled);
     }
   }
   __device__ __forceinline__ void store_tail(__bf16* s, bool scaled, int k0, int kend) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       c[q].zero_if(k0 + kr + RPQ * q >= kend || !colok);
-      c[q].template st<GELU>(s + soff + RPQ * q * LD, sc, scaled);
+      if constexpr (SPLIT) c[q].st_split(s + soff + RPQ * q * LD, LO, sc);
+      else c[q].template st<GELU>(s + soff + RPQ * q * LD, sc, scaled);
     }
   }
 };
@@ -291,14 +309,17 @@ __device__ __forceinline__ void epi_interior(const float* cs, const WmGemm& g, i
 
 // ------------------------------------------------------------------------------------------------------------------
 // bf16 x bf16 instances are held to 168 registers per lane (3 waves per SIMD = 3 workgroups per CU); they need 172 unconstrained
-template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int EPI>
+// SPLIT (compute_mode "split", fp32 operands): every operand tile is staged as a high and a low bf16 image (x = hi + lo) and a
+// product is three MFMAs, hi*hi + hi*lo + lo*hi: 2^-17 relative per term at 3/16 of the fp32-MFMA time (the round-2 STFT trick)
+template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 && EPI != 4 ? 3 : 2)) void gemm_nt_kernel(const WmGemm g, const bool vec_ok, const int tiles_n, const int tiles_m) {
   constexpr int BK = 64, BM = WM * TM * 32, BN = WN * TN * 32, LDA = BK + 8;
-  constexpr int LDB = B_TR ? BN + 32 : BK + 8, BSZ = B_TR ? BK * LDB : BN * LDB;
+  constexpr int LDB = B_TR ? BN + 32 : BK + 8, BSZ1 = B_TR ? BK * LDB : BN * LDB;
+  constexpr int ASZ = (SPLIT ? 2 : 1) * BM * LDA, BSZ = (SPLIT ? 2 : 1) * BSZ1;
   constexpr int NBUF = NT_NBUF;                              // LDS operand buffers (1: more workgroups per CU, one more barrier per k tile)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);          // [2][BM][LDA]
-  __bf16* Bs = As + NBUF * BM * LDA;                         // [NBUF][BSZ]
+  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);          // [NBUF][ASZ]
+  __bf16* Bs = As + NBUF * ASZ;                              // [NBUF][BSZ]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
   int bx, by, bz;
@@ -313,10 +334,10 @@ __global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 && EPI != 4 ? 3 :
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  KcStage<AT, BM, BK, A_GELU> sa;
+  KcStage<AT, BM, BK, A_GELU, SPLIT> sa;
   sa.init(g.A, g.lda, m0, g.M, 0, tid);
-  KcStage<BT, BN, BK, false> sbk;
-  TrStage<BT, BN, BK, false> sbt;
+  KcStage<BT, BN, BK, false, SPLIT> sbk;
+  TrStage<BT, BN, BK, false, SPLIT> sbt;
   if constexpr (B_TR) sbt.init(g.B, g.ldb, n0, g.N, 0, tid); else sbk.init(g.B, g.ldb, n0, g.N, 0, tid);
 
   const int nfull = K / BK, ntiles = (K + BK - 1) / BK;     // tiles [0, nfull) lie completely inside K
@@ -342,7 +363,7 @@ __global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 && EPI != 4 ? 3 :
       sa.load_tail(nx * BK, K);
       if constexpr (B_TR) sbt.load_tail(nx * BK, K); else sbk.load_tail(nx * BK, K);
     }
-    const __bf16* Ab = As + buf * BM * LDA + ((wm * TM) * 32 + r) * LDA;
+    const __bf16* Ab = As + buf * ASZ + ((wm * TM) * 32 + r) * LDA;
     const __bf16* Bb = Bs + buf * BSZ;
     // operand fragments of k-step ks + 1 are read from LDS while the MFMAs of step ks run (at one or two waves per SIMD
     // nothing else hides the LDS latency: waiting for each step's reads in turn parked the wave ~40 % of the loop)
@@ -356,6 +377,29 @@ __global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 && EPI != 4 ? 3 :
         else fb[j] = *reinterpret_cast<const bf16x8*>(Bb + ((wn * TN + j) * 32 + r) * LDB + 16 * ks + 8 * h);
       }
     };
+    if constexpr (SPLIT) {
+      // low-part fragments straight before their use (the split instances run at two waves per SIMD either way)
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 ah[TM], bh[TN], al[TM], bl[TN];
+        frags(ks, ah, bh);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) al[i] = *reinterpret_cast<const bf16x8*>(Ab + BM * LDA + i * 32 * LDA + 16 * ks + 8 * h);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (B_TR) bl[j] = tr_frag(Bb + BSZ1, LDB, (wn * TN + j) * 32, ks, lane);
+          else bl[j] = *reinterpret_cast<const bf16x8*>(Bb + BSZ1 + ((wn * TN + j) * 32 + r) * LDB + 16 * ks + 8 * h);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);     // small terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
     frags(0, a[0], b[0]);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
@@ -368,13 +412,14 @@ __global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 && EPI != 4 ? 3 :
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
     const int nb = NBUF == 2 ? buf ^ 1 : 0;
     if (NBUF == 1) __syncthreads();                           // every wave is done reading the single buffer
     if (nx < nfull) {
-      sa.store_full(As + nb * BM * LDA);
+      sa.store_full(As + nb * ASZ);
       if constexpr (B_TR) sbt.store_full(Bs + nb * BSZ, false); else sbk.store_full(Bs + nb * BSZ);
     } else if (nx < ntiles) {
-      sa.store_tail(As + nb * BM * LDA, nx * BK, K);
+      sa.store_tail(As + nb * ASZ, nx * BK, K);
       if constexpr (B_TR) sbt.store_tail(Bs + nb * BSZ, false, nx * BK, K); else sbk.store_tail(Bs + nb * BSZ, nx * BK, K);
     }
     __syncthreads();
@@ -502,13 +547,13 @@ __global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 && EPI != 4 ? 3 :
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int TBK = 64;                                    // k rows per tile of the weight-gradient kernel (32 KB of loads in flight per workgroup)
 
-template <typename AT, typename BT, bool B_GELU, int TM, int TN>
+template <typename AT, typename BT, bool B_GELU, int TM, int TN, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int klen, const int tiles_n, const int tiles_m,
                                                       const int ksplit, float* __restrict__ part) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 32, LDB = BN + 32;
   constexpr int NBUF = TN_NBUF;                               // 1: half the LDS, twice the workgroups per CU, one more barrier per k tile
-  __shared__ __attribute__((aligned(16))) __bf16 As[NBUF][TBK * LDA];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[NBUF][TBK * LDB];
+  __shared__ __attribute__((aligned(16))) __bf16 As[NBUF][(SPLIT ? 2 : 1) * TBK * LDA];     // SPLIT: high | low image
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[NBUF][(SPLIT ? 2 : 1) * TBK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
   int bx, by, bz;
@@ -533,8 +578,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   float bsum = 0.f;
 
-  TrStage<AT, BM, TBK, false> sa;
-  TrStage<BT, BN, TBK, B_GELU> sb;
+  TrStage<AT, BM, TBK, false, SPLIT> sa;
+  TrStage<BT, BN, TBK, B_GELU, SPLIT> sb;
   sa.init(g.A, g.lda, m0, g.M, kbeg, tid);
   sb.init(g.B, g.ldb, n0, g.N, kbeg, tid);
   const bool scaled = g.kscale != nullptr;                   // host guarantees k_per_scale % TBK == 0 and klen % TBK == 0
@@ -561,6 +606,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int 
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[j] = tr_frag(Bs[buf], LDB, (wn * TN + j) * 32, ks, lane);
     };
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < TBK / 16; ++ks) {
+        bf16x8 ah[TM], bh[TN], al[TM], bl[TN];
+        frags(ks, ah, bh);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) al[i] = tr_frag(As[buf] + TBK * LDA, LDA, (wm * TM + i) * 32, ks, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bl[j] = tr_frag(Bs[buf] + TBK * LDB, LDB, (wn * TN + j) * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
     frags(0, a[0], b[0]);
 #pragma unroll
     for (int ks = 0; ks < TBK / 16; ++ks) {
@@ -573,9 +637,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
     if (g.b_ones) {                                            // column sums of A (bias gradient), see bias_first above
 #pragma unroll 4
-      for (int kr = bias_first; kr < TBK; kr += bias_step) bsum += (float)As[buf][kr * LDA + (tid & (BM - 1))];
+      for (int kr = bias_first; kr < TBK; kr += bias_step) {
+        bsum += (float)As[buf][kr * LDA + (tid & (BM - 1))];
+        if constexpr (SPLIT) bsum += (float)As[buf][TBK * LDA + kr * LDA + (tid & (BM - 1))];
+      }
     }
     const int nb = NBUF == 2 ? buf ^ 1 : 0;
     if (NBUF == 1) __syncthreads();                           // every wave is done reading the single buffer
@@ -643,24 +711,38 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int 
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int EPI>
+template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int EPI, bool SPLIT = false>
 int launch_nt_epi(const WmGemm& g, bool vec_ok, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 64;
   constexpr size_t bsz = B_TR ? BK * (BN + 32) : BN * (BK + 8);
-  constexpr size_t stage = NT_NBUF * 2 * (BM * (BK + 8) + bsz), ctile = sizeof(float) * TM * 32 * (BN + 4);
+  constexpr size_t stage = (SPLIT ? 2 : 1) * NT_NBUF * 2 * (BM * (BK + 8) + bsz), ctile = sizeof(float) * TM * 32 * (BN + 4);
   constexpr size_t smem = stage > ctile ? stage : ctile;
   static bool attr = false;
   if (!attr) {
     if (smem > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, EPI>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, EPI, SPLIT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-  hipLaunchKernelGGL((gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, EPI>), dim3(8 * ((tiles_m + 7) / 8) * tiles_n), dim3(256),
+  wm_gemm_family_tls = WM_FAM_NT;
+  hipLaunchKernelGGL((gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, EPI, SPLIT>), dim3(8 * ((tiles_m + 7) / 8) * tiles_n), dim3(256),
                      smem, st, g, vec_ok, tiles_n, tiles_m);
   WM_CHECK_LAUNCH();
   return WM_OK;
+}
+
+// split-precision launches (fp32 operands and outputs): the general epilogue only
+template <bool B_TR>
+int dispatch_nt_split(const WmGemm& g, hipStream_t st) {
+  const bool vec_ok = al16(g.C) && !(g.ldc & 7) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && !(g.ldr & 3))) &&
+                      (!g.gaux || (al16(g.gaux) && !(g.ldg & 7)));
+  const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  const int64_t t12864 = (int64_t)((g.M + 127) / 128) * ((g.N + 63) / 64);
+  if (g.N <= 32) return launch_nt_epi<float, float, B_TR, false, 4, 1, 2, 1, 3, true>(g, vec_ok, st);
+  if (g.N > 64 && t128 >= 256) return launch_nt_epi<float, float, B_TR, false, 2, 2, 2, 2, 3, true>(g, vec_ok, st);
+  if (t12864 >= 256 || g.M >= 32768) return launch_nt_epi<float, float, B_TR, false, 2, 2, 2, 1, 3, true>(g, vec_ok, st);
+  return launch_nt_epi<float, float, B_TR, false, 2, 2, 1, 1, 3, true>(g, vec_ok, st);
 }
 
 // picks the epilogue specialisation from the operands that are present (3 = general code)
@@ -737,7 +819,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-template <typename AT, typename BT, bool B_GELU, int TM, int TN>
+template <typename AT, typename BT, bool B_GELU, int TM, int TN, bool SPLIT = false>
 int launch_tn(const WmGemm& g, hipStream_t st) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
@@ -752,7 +834,8 @@ int launch_tn(const WmGemm& g, hipStream_t st) {
   klen = (klen + TBK - 1) / TBK * TBK;
   ksplit = (g.K + klen - 1) / klen;
   float* part = (use_part && ksplit > 1) ? g.scratch : nullptr;
-  hipLaunchKernelGGL((gemm_tn_kernel<AT, BT, B_GELU, TM, TN>), dim3(8 * ((ksplit + 7) / 8) * tiles), dim3(256), 0, st, g, klen,
+  wm_gemm_family_tls = WM_FAM_TN;
+  hipLaunchKernelGGL((gemm_tn_kernel<AT, BT, B_GELU, TM, TN, SPLIT>), dim3(8 * ((ksplit + 7) / 8) * tiles), dim3(256), 0, st, g, klen,
                      tiles_n, tiles_m, ksplit, part);
   WM_CHECK_LAUNCH();
   if (g.defer) {                                              // the caller sums the slices later (wm_reduce_jobs)
@@ -789,6 +872,28 @@ int dispatch_tn(const WmGemm& g, hipStream_t st) {
 }  // namespace
 
 // Returns -1 when the launch does not fit the fast kernels (caller falls back to the generic kernel of gemm.hip).
+// compute_mode "split" (mode 2): fp32 storage everywhere, products in split bf16 on the fast kernels.  -1 = shape not covered
+// (the caller then runs the exact fp32-MFMA kernel of gemm.hip, which costs time, not accuracy).
+int wm_gemm_fast_split(const WmGemm& g, hipStream_t st) {
+  if (g.defer) *g.defer = WmReduceJob{};
+  if (g.mode != 2 || g.a_bf16 || g.b_bf16 || g.c_bf16 || g.gaux_bf16 || g.a_op || g.b_op || g.ln_out) return -1;
+  if (!g.a_kc && !g.b_kc && g.atomic_out) {                                     // weight gradient
+    if ((g.M % 4) || (g.N % 4) || (g.lda % 4) || (g.ldb % 4) || g.M < 4 || g.N < 4) return -1;
+    if (g.kscale && (g.k_per_scale <= 0 || g.k_per_scale % TBK)) return -1;
+    if (g.M > 64) return launch_tn<float, float, false, 2, 1, true>(g, st);
+    return launch_tn<float, float, false, 1, 1, true>(g, st);
+  }
+  if (g.a_kc && !g.atomic_out && !g.b_ones && !g.kscale && (g.K % 8) == 0 && g.K >= 8 && (g.lda % 4) == 0) {
+    if (g.b_kc) {
+      if (g.ldb % 4) return -1;
+      return dispatch_nt_split<false>(g, st);
+    }
+    if ((g.N % 8) || (g.ldb % 4) || g.N < 8) return -1;
+    return dispatch_nt_split<true>(g, st);
+  }
+  return -1;
+}
+
 int wm_gemm_fast_bf16(const WmGemm& g, hipStream_t st) {
   if (g.defer) *g.defer = WmReduceJob{};                       // count 0 unless a split-K launch fills it in
   if (g.mode != 1) return -1;

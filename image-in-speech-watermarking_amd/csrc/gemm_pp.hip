@@ -321,6 +321,7 @@ int launch_nt_pp(const WmGemm& g, hipStream_t st) {
     attr = true;
   }
   const int tiles_n = g.N / 256, tiles_m = (g.M + 255) / 256;
+  wm_gemm_family_tls = WM_FAM_NT_PP;
   const char* d = getenv("WM_GEMM_DBG");                          // ablation switches for scripts/gemm_ablate.py (0 in the product)
   hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI>), dim3(8 * ((tiles_m + 7) / 8) * tiles_n), dim3(512), SMEM_B, st, g, tiles_n, tiles_m,
                      d ? atoi(d) : 0);
@@ -340,6 +341,7 @@ int wm_gemm_pp_tn_launch(const WmGemm& g, int klen, int tiles_n, int tiles_m, in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
     attr = true;
   }
+  wm_gemm_family_tls = WM_FAM_TN_PP;
   hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(8 * ((ksplit + 7) / 8) * tiles_n * tiles_m), dim3(512), SMEM_B, st, g, klen, tiles_n, tiles_m,
                      ksplit, part);
   WM_CHECK_LAUNCH();

@@ -177,7 +177,9 @@ class UformerAudio(nn.Module):
     ``(stft_new, noise, wm_pred, wm)``; ``wm_decode`` / ``feature_extract`` as in model.py:2379 / :2345.
 
     Extra (keyword-only, default = reference behaviour):
-      compute_mode   'fp32' (exact-accumulation parity mode) or 'bf16' (bf16 MFMA operands, fp32 accumulate)
+      compute_mode   'fp32' (exact-accumulation parity mode), 'bf16' (bf16 storage of the wide activations, bf16 MFMA operands,
+                     fp32 accumulate) or 'split' (fp32 storage as in 'fp32', every GEMM as three bf16 MFMA products of
+                     hi / lo operand halves: the parity tolerance at 3/16 instead of 1/16 of the matrix rate)
       attack         AttackConfig applied to the waveform between iSTFT and STFT (hook model.py:2461)
       extract_from   'y' (reference, model.py:2508) or 'attacked' (the commented alternative, model.py:2507)
     """
@@ -305,7 +307,7 @@ class UformerAudio(nn.Module):
 
     # ---- reference API -----------------------------------------------------------------------
     def _mode(self):
-        return {"fp32": ops.MODE_FP32, "bf16": ops.MODE_BF16}[self.compute_mode]
+        return {"fp32": ops.MODE_FP32, "bf16": ops.MODE_BF16, "split": ops.MODE_SPLIT}[self.compute_mode]
 
     # bf16 mode stores the WIDE activations (LN outputs, qkv, attention output, LeFF hidden tensors, im2col buffers and
     # their gradients) and a copy of the weights in bf16; the residual stream, parameters, gradients and LN statistics
@@ -473,7 +475,7 @@ class UformerAudio(nn.Module):
         ops.linear_fwd(xn1, W(pre + "attn.qkv.w"), P[pre + "attn.qkv.b"], qkv, mode)
         o = H(dev, M, C)
         lse = _E(dev, M, C // 32) if half else None
-        ops.winattn_fwd(qkv, P[pre + "attn.relative_position_bias_table"], o, B, hw, C, shift, mode, lse=lse)
+        ops.winattn_fwd(qkv, P[pre + "attn.relative_position_bias_table"], o, B, hw, C, shift, mode & 1, lse=lse)   # split: fp32 kernels
         x1 = _E(dev, M, C)
         xn2, mean2, rstd2 = H(dev, M, C), _E(dev, M), _E(dev, M)
         if half and ops.ln_fusable(M, C, C, mode):
@@ -540,7 +542,7 @@ class UformerAudio(nn.Module):
                               scratch=sg2, defer=jobs.take(1))
         dqkv = H(dev, M, 3 * C)
         ops.winattn_bwd(qkv, P[pre + "attn.relative_position_bias_table"], do, dqkv,
-                        G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, mode, out=o, lse=lse,
+                        G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, mode & 1, out=o, lse=lse,
                         scratch=sat, defer=jobs.take(1))
         dxn1 = H(dev, M, C)
         ops.linear_bwd_input(dqkv, W(pre + "attn.qkv.w"), dxn1, mode, wT=WT(pre + "attn.qkv.w"))

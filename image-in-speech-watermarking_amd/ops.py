@@ -10,7 +10,7 @@ import torch
 
 from ._lib import lib, check, ptr, WmGemm, WmConv, WmAttack, WmReduceJob, WmWaveAttack
 
-MODE_FP32, MODE_BF16 = 0, 1
+MODE_FP32, MODE_BF16, MODE_SPLIT = 0, 1, 2      # SPLIT: fp32 storage, GEMMs as three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
 
 
 def _stream():

@@ -24,6 +24,8 @@ def _gemm_cost(a):
         byts += 4.0 * M * N
     if kw.get("gaux") is not None:
         byts += kw["gaux"].element_size() * M * N
+    if kw.get("ln") is not None:                              # fused LayerNorm of the output rows: bf16 rows + mean / rstd
+        byts += 2.0 * M * N + 8.0 * M
     return flops, byts
 
 
@@ -72,7 +74,10 @@ class KernelTimer:
             # kernel FAMILY as it appears in a rocprofv3 kernel trace: gemm_nt_kernel<...> runs forward and input-gradient
             # GEMMs, gemm_tn_kernel<...> the weight gradients (their split-K sums are deferred to reduce_jobs_kernel inside
             # LeWin blocks, summed by splitk_reduce_kernel elsewhere), gemm_kernel<...> is the fp32 parity-mode kernel
-            fam = "gemm_kernel(fp32)" if not mode else ("gemm_tn_kernel" if lay == "dW" else "gemm_nt_kernel")
+            fam = ("gemm_kernel", "gemm_nt_kernel", "gemm_tn_kernel", "gemm_nt_pp_kernel", "gemm_tn_pp_kernel", "gemm_nt_big_kernel",
+                   "gemm_tn_big_kernel")[int(ops.lib.wm_last_gemm_family())]      # what the dispatcher launched (called after fn)
+            if fam == "gemm_kernel" and not mode:
+                fam = "gemm_kernel(fp32)"
             if self.detail:
                 return f"{fam}_{lay}_M{M}_N{N}_K{K}", mode
             return fam, mode
@@ -92,7 +97,7 @@ class KernelTimer:
     def __enter__(self):
         for name in dir(ops):
             fn = getattr(ops, name)
-            if not callable(fn) or name.startswith("_") or name in ("check", "ptr", "conv_desc", "linear_fwd",
+            if not callable(fn) or name.startswith("_") or name in ("check", "ptr", "conv_desc", "linear_fwd", "ln_fusable",
                                                                      "linear_bwd_input", "linear_bwd_weight"):
                 continue
             if getattr(fn, "__module__", "") != ops.__name__:
@@ -156,9 +161,10 @@ STFT_PATH = ("istft_fwd", "stft_fwd", "istft_bwd", "stft_bwd", "attack_fwd", "at
 # KernelTimer key -> __global__ functions (rocprofv3 kernel families) that carry it
 FAMILY_KERNELS = {"reduce_jobs": ["reduce_jobs_kernel"], "winattn_bwd_bf16": ["attn_bwd_fast_kernel"],
                   "winattn_fwd_bf16": ["attn_fwd_fast_kernel"], "layernorm_fwd": ["ln_fwd_kernel"],
-                  "layernorm_bwd": ["ln_bwd_kernel"], "istft_fwd": ["synth_mfma_kernel"], "stft_bwd": ["synth_mfma_kernel"],
-                  "stft_fwd": ["analysis_mfma_kernel"], "istft_bwd": ["analysis_mfma_kernel"], "attack_fwd": ["attack_fwd_kernel"],
-                  "attack_bwd": ["attack_bwd_kernel"]}
+                  "layernorm_bwd": ["ln_bwd_kernel"], "istft_fwd": ["synth_mfma_kernel<false>"], "stft_bwd": ["synth_mfma_kernel<true>"],
+                  "stft_fwd": ["analysis_mfma_kernel<false>"], "istft_bwd": ["analysis_mfma_kernel<true>"],
+                  "attack_fwd": ["attack_fwd_kernel"], "attack_bwd": ["attack_bwd_kernel"],
+                  }
 
 
 def time_stft_path(wm, batch, attack_cfg, reps=20):
@@ -238,10 +244,12 @@ def pmc_traffic(kernel_family, path):
     tot, launches = 0.0, 0
     for nm in names:
         f = fams.get(nm)
-        if not f or f.get("hbm_bytes") is None:
+        if not f:
+            continue                                         # a member kernel that did not run at this batch
+        if f.get("hbm_bytes") is None:
             return None
         tot += f["hbm_bytes"]
-        launches = max(launches, f["launches"])
+        launches += f["launches"]
     return tot / launches if launches else None
 
 

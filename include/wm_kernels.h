@@ -77,6 +77,9 @@ typedef struct WmGemm {
 int32_t wm_gemm_ln_fusable(int32_t M, int32_t N, int32_t K, int32_t mode, int32_t a_bf16);
 int64_t wm_gemm_scratch_floats(void);
 int wm_gemm(const WmGemm* g, void* stream);
+/* profiling aid: the kernel family the last wm_gemm call of this host thread launched: 0 gemm_kernel (fp32 MFMA / generic), 1 gemm_nt_kernel,
+ * 2 gemm_tn_kernel, 3 gemm_nt_pp_kernel, 4 gemm_tn_pp_kernel, 5 gemm_nt_big_kernel, 6 gemm_tn_big_kernel */
+int32_t wm_last_gemm_family(void);
 
 /* ---- LayerNorm (+ window modulator) — model.py:982,1017 (norm1/norm2), :996-997 (modulator) ---- */
 int wm_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* modulator,

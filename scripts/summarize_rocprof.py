@@ -77,13 +77,28 @@ def main():
     print("wrote", prefix + ".json")
 
 
+# kernels whose template instances are different operations of the step (forward transform vs the other transform's adjoint):
+# their PMC traffic is kept per instance
+PER_INSTANCE = ("synth_mfma_kernel", "analysis_mfma_kernel")
+
+
 def family(name):
-    """Kernel family = the __global__ function without template arguments (what bench.py's roofline object names)."""
-    m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)(I|E)", name)
+    """Kernel family = the __global__ function without template arguments (what bench.py's roofline object names); the STFT
+    kernels keep their <ADJ> instance (synth_mfma_kernel<false> = iSTFT forward, <true> = STFT backward, ...)."""
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)(I|E)(.*)", name)
     if m:
-        return m.group(1)
+        base = m.group(1)
+        if base in PER_INSTANCE:
+            b = re.match(r"Lb([01])E", m.group(3))
+            return f"{base}<{'true' if b and b.group(1) == '1' else 'false'}>"
+        return base
     name = re.sub(r"\(anonymous namespace\)::", "", re.sub(r"^void ", "", name))
-    return re.split(r"[<(]", name)[0]
+    base = re.split(r"[<(]", name)[0]
+    if base in PER_INSTANCE:
+        b = re.search(r"<\s*(true|false|\(bool\)[01]|[01])\s*>", name)
+        flag = b.group(1) if b else "false"
+        return f"{base}<{'true' if flag in ('true', '1', '(bool)1') else 'false'}>"
+    return base
 
 
 def mfma_counters(mfma_dir):

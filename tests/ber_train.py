@@ -110,7 +110,7 @@ def oracle_parity(wm, net, x, msg, tiles=8):
     z = wm.ops.awgn_noise(wm.attacks.rank_seed(cfg.seed), net._step_t, tiles, 8002).double().cpu().numpy()
     hip = {}
     try:
-        for mode in dict.fromkeys((mode0, "fp32")):
+        for mode in dict.fromkeys((mode0, "fp32", "split")):
             net.compute_mode = mode
             for name, att, ext in (("no_attack", None, "y"), ("attacked", cfg, "attacked")):
                 net.attack, net.extract_from = att, ext
@@ -137,7 +137,7 @@ def oracle_parity(wm, net, x, msg, tiles=8):
         c = cpu[name]
         margin = float((c[3] - 0.5).abs().min())
         e = {"cpu_fp32": ber_of(c[3], bits), "cpu_min_margin_from_threshold": margin}
-        for mode in dict.fromkeys((mode0, "fp32")):
+        for mode in dict.fromkeys((mode0, "fp32", "split")):
             h = hip[mode, name]
             e[f"hip_{mode}"] = ber_of(h[3], bits)
             e[f"hip_{mode}_bits_equal_cpu"] = float((h[3].round().clamp(0, 1) == c[3].round().clamp(0, 1)).float().mean())

@@ -44,10 +44,17 @@ def test_state_dict_is_reference_compatible(net, golden):
     assert all(p.is_cuda for p in net.parameters())
 
 
-def test_g3_eval_forward_matches_reference_golden(net, golden):
+# the two modes held to north_star's bound (payload bits exact, 1e-4 relative on the spectrogram / loss tensors): "fp32" (fp32 MFMA,
+# exact accumulation) and "split" (fp32 storage, every GEMM as three bf16 MFMA products of hi / lo halves, round 3)
+PARITY_MODES = ["fp32", "split"]
+
+
+@pytest.mark.parametrize("pmode", PARITY_MODES)
+def test_g3_eval_forward_matches_reference_golden(net, golden, pmode):
     g = golden("g3_model_eval")
+    load_synth(net)
     net.eval()
-    net.compute_mode = "fp32"
+    net.compute_mode = pmode
     x, msg = synth_tile(2, "g3_x").cuda(), synth_bits("g3_msg", (2, 1, 32, 32)).cuda()
     with torch.no_grad():
         out = net(x, msg)
@@ -61,6 +68,7 @@ def test_g3_eval_forward_matches_reference_golden(net, golden):
         assert rel(net.wm_decode(x), g["wm_decode_x"]) <= 1e-4
         y, wmp = net.feature_extract(x, msg)
     assert rel(y[:, :, :8, :8], g["fe_y"]) <= 1e-4 and rel(wmp, g["fe_wm"]) <= 1e-4
+    net.compute_mode = "fp32"
 
 
 def _scales_from_golden_masks(net, masks):
@@ -76,11 +84,12 @@ def _scales_from_golden_masks(net, masks):
     return out.cuda()
 
 
-def test_g4_train_step_gradients_match_reference_golden(net, golden, wm):
+@pytest.mark.parametrize("pmode", PARITY_MODES)
+def test_g4_train_step_gradients_match_reference_golden(net, golden, wm, pmode):
     g = golden("g4_model_train")
     load_synth(net)
     net.train()
-    net.compute_mode = "fp32"
+    net.compute_mode = pmode
     x, msg = synth_tile(2, "g4_x").cuda(), synth_bits("g4_msg", (2, 1, 32, 32)).cuda()
     scales = _scales_from_golden_masks(net, T(g["masks"]))
     net.zero_grad(set_to_none=True)
@@ -99,11 +108,14 @@ def test_g4_train_step_gradients_match_reference_golden(net, golden, wm):
     # one fused AdamW step reproduces torch.optim.AdamW (audio_uformer_stft.py:252-255)
     opt = wm.FusedAdamW(net, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
     opt.step()
+    # (AdamW's first step moves every element by ~lr * sign(g): an element whose gradient is a rounding error away from zero
+    # lands up to 2 lr = 4e-4 ... in practice a few 1e-6 elsewhere; split mode: one element in 32 768 was 3.1e-6 off)
     for k in [k for k in g.files if k.startswith("p_")]:
         name = k[2:].replace("__", ".")
-        np.testing.assert_allclose(net.get_parameter(name).detach().cpu().numpy(), g[k], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(net.get_parameter(name).detach().cpu().numpy(), g[k], rtol=1e-4, atol=2e-6 if pmode == "fp32" else 6e-6)
     unused = net.get_parameter("encoder.input_proj.proj.0.weight")
     assert torch.equal(unused.detach().cpu(), load_synth(O.UformerAudio()).encoder.input_proj.proj[0].weight.detach())
+    net.compute_mode = "fp32"
 
 
 def test_bf16_mode_bits_and_deviation(net, golden):
@@ -351,13 +363,14 @@ def _full_attack_oracle(wm, net, B):
     return cfg, (lambda w: AT.attack_chain(w.double(), resample=True, snr_db=20.0, z=z.double(), lowpass=True, amp=0.8).float())
 
 
-def test_config3_full_attack_stack_forward_and_gradients(wm):
+@pytest.mark.parametrize("pmode", PARITY_MODES)
+def test_config3_full_attack_stack_forward_and_gradients(wm, pmode):
     """BASELINE config 3: resample + AWGN (20 dB, replayed) + low-pass + x0.8 between iSTFT and STFT, extractor on the
     attacked spectrogram; train mode (drop_path_rate = 0), fp32 parity mode: outputs, loss terms and gradients of
     parameters on both sides of the attack against the oracle (autograd through its torch restatement of the chain)."""
     B = 2
     x, msg = synth_tile(B, "c3_x"), synth_bits("c3_msg", (B, 1, 32, 32))
-    m = wm.UformerAudio(modulator=True, drop_path_rate=0.0, compute_mode="fp32")
+    m = wm.UformerAudio(modulator=True, drop_path_rate=0.0, compute_mode=pmode)
     load_synth(m)
     m = m.cuda().train()
     m._ensure_runtime(torch.device("cuda"))
@@ -386,7 +399,8 @@ def test_config3_full_attack_stack_forward_and_gradients(wm):
         assert e <= 3e-3, (n, e)
 
 
-def test_config5_ten_tile_clips_quadrant_payload(wm):
+@pytest.mark.parametrize("pmode", PARITY_MODES)
+def test_config5_ten_tile_clips_quadrant_payload(wm, pmode):
     """BASELINE config 5 / row A14: 2 clips x 10 tiles (10 s at 16 kHz through the device data-prep STFT), a 64 x 64
     grayscale payload per clip cut into quadrants over the tiles, full attack stack (AWGN replayed), train mode, fp32
     parity mode, against the oracle: outputs, loss, selected gradients; decoded quadrants re-assembled bit-exactly."""
@@ -398,7 +412,7 @@ def test_config5_ten_tile_clips_quadrant_payload(wm):
     x = tiles.view(clips, n_per, 2, 128, 128)[:, :tpc].reshape(B, 2, 128, 128).contiguous()
     img = torch.rand(clips, 1, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
     msg = wm.dataprep.payload_for_tiles(img, tpc).contiguous()
-    m = wm.UformerAudio(modulator=True, drop_path_rate=0.0, compute_mode="fp32")
+    m = wm.UformerAudio(modulator=True, drop_path_rate=0.0, compute_mode=pmode)
     load_synth(m)
     m = m.cuda().train()
     m.attack, m.extract_from = wm.AttackConfig.full_stack(), "attacked"
