@@ -106,13 +106,18 @@ def test_g4_train_step_gradients_match_reference_golden(net, golden, wm, pmode):
         name = k[2:].replace("__", ".")
         assert rel(net.get_parameter(name).grad, g[k]) <= 2e-3, (name, rel(net.get_parameter(name).grad, g[k]))
     # one fused AdamW step reproduces torch.optim.AdamW (audio_uformer_stft.py:252-255)
+    # AdamW's first step moves an element by lr * g / (|g| + eps): where |g| is within a few orders of eps = 1e-8 the step is a
+    # steep function of g (a gradient that is a rounding error away from zero lands anywhere in +-lr), so those elements are only
+    # held to the step bound; everywhere else the parameter is compared elementwise
+    grads = {n: net.get_parameter(n).grad.detach().clone() for n in (k[2:].replace("__", ".") for k in g.files if k.startswith("p_"))}
     opt = wm.FusedAdamW(net, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
     opt.step()
-    # (AdamW's first step moves every element by ~lr * sign(g): an element whose gradient is a rounding error away from zero
-    # lands up to 2 lr = 4e-4 ... in practice a few 1e-6 elsewhere; split mode: one element in 32 768 was 3.1e-6 off)
     for k in [k for k in g.files if k.startswith("p_")]:
         name = k[2:].replace("__", ".")
-        np.testing.assert_allclose(net.get_parameter(name).detach().cpu().numpy(), g[k], rtol=1e-4, atol=2e-6 if pmode == "fp32" else 6e-6)
+        got, want = net.get_parameter(name).detach().cpu().numpy(), g[k]
+        firm = (grads[name].abs() > 1e-5).cpu().numpy()                    # |g| >= 1000 eps: the step is lr * sign(g) to 1e-3
+        np.testing.assert_allclose(got[firm], want[firm], rtol=1e-4, atol=2e-6)
+        assert firm.mean() > 0.5 and np.abs(got - want).max() <= 4.1e-4, (name, firm.mean(), np.abs(got - want).max())
     unused = net.get_parameter("encoder.input_proj.proj.0.weight")
     assert torch.equal(unused.detach().cpu(), load_synth(O.UformerAudio()).encoder.input_proj.proj[0].weight.detach())
     net.compute_mode = "fp32"
