@@ -353,6 +353,7 @@ int wm_gemm_big_tn_bf16(const WmGemm& g, hipStream_t st) {
   int ksplit = g.ksplit > 0 ? g.ksplit : (256 + tiles - 1) / tiles;
   const int64_t mn = (int64_t)g.M * g.N;
   if ((int64_t)ksplit * mn > g.scratch_floats) ksplit = (int)(g.scratch_floats / mn);
+  if (ksplit > g.K / 512) ksplit = g.K / 512;                      // as in gemm_fast.hip launch_tn: no slice under 512 tokens
   if (ksplit < 1) return -1;
   int klen = (g.K + ksplit - 1) / ksplit;
   klen = (klen + 63) / 64 * 64;
