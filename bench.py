@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--segmented", action="store_true",
                     help="capture the step as the multi-rank chain of graphs (cut at the gradient buckets) on one rank too")
+    ap.add_argument("--no-secondary-legs", action="store_true", help="skip the config-5 (10 s clips) and fp32-mode rates")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline and the BER / deviation parity block)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--ber-train-steps", type=int, default=1600,
@@ -431,6 +432,32 @@ def main():
             del step_p
         finally:
             net.compute_mode = a.mode
+    secondary = None
+    if a.mode == "bf16" and not a.no_secondary_legs and a.clip_seconds == 1 and world == 1 and attacked:
+        # the rates DESIGN.md quoted in prose, measured in this run — BASELINE config 5's per-GPU workload
+        # (2 clips of 10 s = 20 tiles, 64 x 64 grayscale payload as quadrants) and the exact fp32 mode at B = 12
+        import copy
+        secondary = {}
+        a5 = copy.copy(a)
+        a5.clip_seconds, a5.batch = 10, 20
+        x5, m5 = make_batch(wm, a5, rank, dev)
+        st5 = wm.TrainStep(net, opt, 20, attack=attack, extract_from=extract_from, use_graph=not a.no_graph)
+        dt5 = timed(st5, x5, m5, 10, 3)
+        secondary["config5"] = {"workload": workload_name(a5, attacked), "tiles_per_gpu": 20,
+                                "value": 20 * TILE_SECONDS * 10 / dt5, "ms_per_step": dt5 / 10 * 1e3, "steps": 10}
+        st5.release()
+        del st5, x5, m5
+        net.compute_mode = "fp32"
+        try:
+            fb = min(12, a.batch)
+            stf = wm.TrainStep(net, opt, fb, attack=attack, extract_from=extract_from, use_graph=not a.no_graph)
+            dtf = timed(stf, x[:fb], msg[:fb], 5, 2)
+            secondary["fp32_mode"] = {"mode": "fp32 (fp32 storage, fp32-input MFMA / VALU arithmetic throughout)", "tiles_per_gpu": fb,
+                                      "value": fb * TILE_SECONDS * 5 / dtf, "ms_per_step": dtf / 5 * 1e3, "steps": 5}
+            stf.release()
+            del stf
+        finally:
+            net.compute_mode = a.mode
     result = {
         "metric": "audio-sec/s per train step (enc+attack+dec)", "value": world * a.batch * TILE_SECONDS * a.steps / dt,
         "unit": "audio-sec/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -448,6 +475,8 @@ def main():
         result["parity_mode"] = parity_leg
     if identity is not None:
         result["identity_attack"] = identity
+    if secondary:
+        result.update(secondary)
     if ber is not None:
         result["ber"] = ber
     if allreduce is not None:

@@ -16,6 +16,10 @@ int wm_attn_fast_fwd(const __bf16* qkv, const float* table, __bf16* out, float* 
 int wm_attn_fast_bwd(const __bf16* qkv, const float* table, const __bf16* out, const float* lse, const __bf16* dout,
                      __bf16* dqkv, float* dtable, float* scratch, WmReduceJob* defer, int B, int hw, int C, int shift,
                      hipStream_t st);
+// compute_mode "split" (attn_split.hip): fp32 storage, split-precision bf16 MFMA products
+int wm_attn_split_fwd(const float* qkv, const float* table, float* out, float* lse, int B, int hw, int C, int shift, hipStream_t st);
+int wm_attn_split_bwd(const float* qkv, const float* table, const float* out, const float* lse, const float* dout, float* dqkv,
+                      float* dtable, float* scratch, WmReduceJob* defer, int B, int hw, int C, int shift, hipStream_t st);
 
 namespace {
 
@@ -320,6 +324,8 @@ extern "C" int wm_winattn_fwd(const void* qkv, const float* bias_table, void* ou
   if (mode == 1 && io_bf16)
     return wm_attn_fast_fwd(static_cast<const __bf16*>(qkv), bias_table, static_cast<__bf16*>(out), lse, B, hw, C, shift, st);
   if (mode == 1) return attn_fwd_launch<__bf16, float>(qkv, bias_table, out, lse, g, B, st);
+  if (mode == 2)                                               // fp32 storage, split-precision products
+    return wm_attn_split_fwd(static_cast<const float*>(qkv), bias_table, static_cast<float*>(out), lse, B, hw, C, shift, st);
   return WM_EINVAL;
 }
 
@@ -337,7 +343,10 @@ extern "C" int wm_winattn_bwd(const void* qkv, const float* bias_table, const vo
   if (mode == 1 && io_bf16 && out && lse)                 // forward output + row log-sum-exp available: attn_fast.hip
     return wm_attn_fast_bwd(static_cast<const __bf16*>(qkv), bias_table, static_cast<const __bf16*>(out), lse,
                             static_cast<const __bf16*>(dout), static_cast<__bf16*>(dqkv), dbias_table, scratch, defer, B, hw, C, shift, st);
-  if (mode == 0) return attn_bwd_launch<float, float>(qkv, bias_table, dout, dqkv, dbias_table, g, B, st);
+  if (mode == 2 && out && lse)
+    return wm_attn_split_bwd(static_cast<const float*>(qkv), bias_table, static_cast<const float*>(out), lse,
+                             static_cast<const float*>(dout), static_cast<float*>(dqkv), dbias_table, scratch, defer, B, hw, C, shift, st);
+  if (mode == 0 || mode == 2) return attn_bwd_launch<float, float>(qkv, bias_table, dout, dqkv, dbias_table, g, B, st);
   if (mode == 1 && io_bf16) return attn_bwd_launch<__bf16, __bf16>(qkv, bias_table, dout, dqkv, dbias_table, g, B, st);
   if (mode == 1) return attn_bwd_launch<__bf16, float>(qkv, bias_table, dout, dqkv, dbias_table, g, B, st);
   return WM_EINVAL;

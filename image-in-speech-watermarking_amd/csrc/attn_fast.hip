@@ -17,38 +17,11 @@
 #include "common.h"
 #include "../../include/wm_kernels.h"
 
+#include "attn_geom.h"
+
 namespace {
+using namespace attnk;
 
-constexpr int LDK = 40;                                       // LDS row stride (bf16): 80 B, 16-B aligned chunks
-constexpr float kScale = 0.17677669529663687f;                // head_dim ** -0.5
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;    // one 16-byte chunk (native vector: stays in registers)
-
-struct Geom {
-  int hw, shift, nw, C, heads;
-  __device__ __forceinline__ int wrap(int v) const { return v >= hw ? v - hw : v; }
-  __device__ __forceinline__ int token_row(int b, int wy, int wx, int p) const {
-    return (b * hw + wrap(wy * 8 + (p >> 3) + shift)) * hw + wrap(wx * 8 + (p & 7) + shift);
-  }
-  __device__ __forceinline__ int region1(int ii) const { return ii < hw - 8 ? 0 : (ii < hw - shift ? 1 : 2); }
-  __device__ __forceinline__ int region(int wy, int wx, int p) const {          // 0 everywhere when there is no shift
-    return shift ? 3 * region1(wy * 8 + (p >> 3)) + region1(wx * 8 + (p & 7)) : 0;
-  }
-};
-
-// as-it-lies [k rows][32 columns] LDS image -> MFMA operand (lane l: column l & 31).
-// perm == false: k slot (h, j) = row0 + 8h + j;  perm == true: row0 + 8(j>>2) + 4h + (j&3)  (accumulator row order)
-__device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int row0, int lane, bool perm) {
-  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, h = g >> 1;
-  const __bf16* a = tile + (row0 + (perm ? 4 * h : 8 * h) + q) * LDK + 16 * (g & 1) + 4 * p;
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + (perm ? 8 : 4) * LDK));
-  bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return f;
-}
-__device__ __forceinline__ bf16x8 row_frag(const __bf16* tile, int row, int ks, int h) {
-  return *reinterpret_cast<const bf16x8*>(tile + row * LDK + 16 * ks + 8 * h);
-}
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int ks) {
   bf16x8 f;
 #pragma unroll
@@ -74,17 +47,6 @@ __device__ __forceinline__ void tile_load(u32x4 (&c)[4], const __bf16* __restric
 __device__ __forceinline__ void tile_to_lds(__bf16* dst, const u32x4 (&c)[4], int lane) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(dst + ((lane >> 2) + 16 * it) * LDK + 8 * (lane & 3)) = c[it];
-}
-
-// blocks are dealt round-robin to the 8 XCDs: renumber so that consecutive virtual ids (the heads of one window, which
-// share 128-byte lines of q|k|v) land on the same XCD's L2
-__device__ __forceinline__ int virtual_block(int id, int n) { return (n & 7) ? id : (id & 7) * (n >> 3) + (id >> 3); }
-
-__device__ __forceinline__ void win_pos(int w, int nw, int& b, int& wy, int& wx) {
-  b = w / (nw * nw);
-  const int wr = w - b * nw * nw;
-  wy = wr / nw;
-  wx = wr - wy * nw;
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward
@@ -389,14 +351,6 @@ __global__ __launch_bounds__(256) void bias_grad_reduce_kernel(const float* __re
   atomicAdd(dtable + t * heads + head, (s0 + s1) + (s2 + s3));
 }
 
-// persistent grid: `waves_per_cu` resident single-wave workgroups on each of the 256 CUs, a whole number of chunks per head
-void grid_for(int nwin, int heads, int waves_per_cu, int& blocks, int& nchunk) {
-  nchunk = (256 * waves_per_cu) / heads;
-  if (nchunk < 1) nchunk = 1;
-  if (nchunk > nwin) nchunk = nwin;
-  blocks = nchunk * heads;
-}
-
 }  // namespace
 
 int wm_attn_fast_fwd(const __bf16* qkv, const float* table, __bf16* out, float* lse, int B, int hw, int C, int shift,
@@ -429,12 +383,16 @@ int wm_attn_fast_bwd(const __bf16* qkv, const float* table, const __bf16* out, c
     *defer = jb;
     if (scratch) return WM_OK;
   }
-  if (scratch) {
-    int segs = nchunk / 16 < 1 ? 1 : (nchunk / 16 > 32 ? 32 : nchunk / 16);
-    const int per = (nchunk + segs - 1) / segs;
-    segs = (nchunk + per - 1) / per;
-    hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(g.heads, segs), dim3(256), 0, st, scratch, dtable, g.heads, nchunk, per);
-    WM_CHECK_LAUNCH();
-  }
+  if (scratch) return wm_attn_bias_reduce(scratch, dtable, g.heads, nchunk, st);
+  return WM_OK;
+}
+
+// dtable[t][head] += the nchunk per-block bins of a backward launch that was not deferred (also used by attn_split.hip)
+int wm_attn_bias_reduce(const float* scratch, float* dtable, int heads, int nchunk, hipStream_t st) {
+  int segs = nchunk / 16 < 1 ? 1 : (nchunk / 16 > 32 ? 32 : nchunk / 16);
+  const int per = (nchunk + segs - 1) / segs;
+  segs = (nchunk + per - 1) / per;
+  hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(heads, segs), dim3(256), 0, st, scratch, dtable, heads, nchunk, per);
+  WM_CHECK_LAUNCH();
   return WM_OK;
 }

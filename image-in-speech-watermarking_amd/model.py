@@ -474,8 +474,8 @@ class UformerAudio(nn.Module):
         qkv = H(dev, M, 3 * C)
         ops.linear_fwd(xn1, W(pre + "attn.qkv.w"), P[pre + "attn.qkv.b"], qkv, mode)
         o = H(dev, M, C)
-        lse = _E(dev, M, C // 32) if half else None
-        ops.winattn_fwd(qkv, P[pre + "attn.relative_position_bias_table"], o, B, hw, C, shift, mode & 1, lse=lse)   # split: fp32 kernels
+        lse = _E(dev, M, C // 32) if mode else None                # the MFMA kernels (bf16 and split) keep the row log-sum-exp
+        ops.winattn_fwd(qkv, P[pre + "attn.relative_position_bias_table"], o, B, hw, C, shift, mode, lse=lse)
         x1 = _E(dev, M, C)
         xn2, mean2, rstd2 = H(dev, M, C), _E(dev, M), _E(dev, M)
         if half and ops.ln_fusable(M, C, C, mode):
@@ -542,7 +542,7 @@ class UformerAudio(nn.Module):
                               scratch=sg2, defer=jobs.take(1))
         dqkv = H(dev, M, 3 * C)
         ops.winattn_bwd(qkv, P[pre + "attn.relative_position_bias_table"], do, dqkv,
-                        G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, mode & 1, out=o, lse=lse,
+                        G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, mode, out=o, lse=lse,
                         scratch=sat, defer=jobs.take(1))
         dxn1 = H(dev, M, C)
         ops.linear_bwd_input(dqkv, W(pre + "attn.qkv.w"), dxn1, mode, wT=WT(pre + "attn.qkv.w"))

@@ -16,7 +16,7 @@ P=$OUT/prof_${R}_$TAG
 mkdir -p $P
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-QUIET="--no-cpu-baseline --no-kernel-timing --no-reference-batch --no-identity-leg --no-parity-mode-leg --ber-train-steps 0"
+QUIET="--no-cpu-baseline --no-kernel-timing --no-reference-batch --no-identity-leg --no-parity-mode-leg --no-secondary-legs --ber-train-steps 0"
 SID=$(python -c "import importlib; print(importlib.import_module('image-in-speech-watermarking_amd.profiling').source_id())")
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 bench.py --steps 5 --warmup 2 $QUIET $ARGS > $P/trace.log 2>&1 || { tail -5 $P/trace.log; exit 1; }
 python scripts/summarize_rocprof.py $P/trace $P/${R}_trace

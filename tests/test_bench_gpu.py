@@ -72,8 +72,10 @@ def test_default_line_carries_config3_roofline_and_ber():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["config"]["baseline_config"] == 3 and line["dtype"] == "bf16"
-    for k in ("roofline", "cpu_baseline", "ber", "mfma_path", "roofline_stft_path"):
+    for k in ("roofline", "cpu_baseline", "ber", "mfma_path", "roofline_stft_path", "parity_mode", "config5", "fp32_mode"):
         assert k in line, k
+    assert line["config5"]["tiles_per_gpu"] == 20 and "10 s 16 kHz clips" in line["config5"]["workload"] and line["config5"]["value"] > 0
+    assert line["fp32_mode"]["value"] > 0 and line["parity_mode"]["value"] > 0
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     ber = line["ber"]
     assert ber["no_attack"]["hip_fp32_bits_equal_cpu"] == 1.0 and ber["attacked"]["hip_fp32_bits_equal_cpu"] == 1.0

@@ -196,6 +196,39 @@ def test_winattn_fwd_bwd(wm, mode, hw, C, shift):
         assert_close(dt2, table.grad, TOL[mode] * 2, "attn dtable (fast)")
 
 
+@pytest.mark.parametrize("hw,C,shift,B", [(16, 64, 0, 2), (16, 64, 4, 2), (8, 128, 0, 3), (32, 32, 4, 2), (64, 32, 4, 1), (8, 512, 0, 5)])
+def test_winattn_split_precision(wm, hw, C, shift, B):
+    """compute_mode "split" (mode 2, attn_split.hip): fp32 storage, every product as three bf16 MFMAs of hi / lo halves.
+    Against the float64 restatement at north_star's 1e-4 (measured ~1e-6), with and without a scratch / deferred bias-table sum,
+    and against the exact fp32 kernels (mode 0)."""
+    ops = wm.ops
+    heads = C // 32
+    qkv = synth_array(f"sqkv{hw}{C}", (B * hw * hw, 3 * C)).double().requires_grad_()
+    table = (0.5 * synth_array(f"stab{C}", (225, heads))).double().requires_grad_()
+    ref = ref_winattn(qkv, table, B, hw, C, shift)
+    do = synth_array(f"sdo{hw}{C}", ref.shape).double()
+    ref.backward(do)
+    qd, td, dd = dev(qkv.detach().float()), dev(table.detach().float()), dev(do.float())
+    out, lse = torch.empty(B * hw * hw, C, device="cuda"), torch.empty(B * hw * hw, heads, device="cuda")
+    ops.winattn_fwd(qd, td, out, B, hw, C, shift, 2, lse=lse)
+    assert_close(out, ref.detach(), 2e-5, "split attn fwd")
+    out0 = torch.empty_like(out)
+    ops.winattn_fwd(qd, td, out0, B, hw, C, shift, 0)
+    assert_close(out, out0, 2e-5, "split attn fwd vs the fp32 kernel")
+    dqkv, dtab = torch.full_like(qd, float("nan")), torch.zeros_like(td)
+    ops.winattn_bwd(qd, td, dd, dqkv, dtab, B, hw, C, shift, 2, out=out, lse=lse)
+    assert_close(dqkv, qkv.grad, 1e-4, "split attn dqkv")
+    assert_close(dtab, table.grad, 1e-4, "split attn dtable")
+    # per-block bins through the scratch buffer, summed by the deferred-reduction launch
+    scr = torch.empty(int(wm.lib.wm_winattn_bwd_scratch_floats()), device="cuda")
+    jobs = ops.ReduceJobs()
+    dq2, dt2 = torch.empty_like(qd), torch.zeros_like(td)
+    ops.winattn_bwd(qd, td, dd, dq2, dt2, B, hw, C, shift, 2, out=out, lse=lse, scratch=scr, defer=jobs.take(1))
+    ops.reduce_jobs(jobs)
+    assert torch.equal(dq2, dqkv)
+    assert_close(dt2, table.grad, 1e-4, "split attn dtable (deferred)")
+
+
 # ------------------------------------------------------------------------------------ dwconv
 @pytest.mark.parametrize("hw,Ch", [(16, 128), (8, 64), (32, 256), (64, 64), (128, 64)])   # hw >= 64: strip-walking forward
 def test_dwconv_fwd_bwd(wm, hw, Ch):
