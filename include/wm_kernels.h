@@ -99,11 +99,12 @@ int wm_layernorm_bwd(const void* dy, int32_t dy_bf16, const float* x, const floa
 
 /* ---- 8x8 window attention — model.py:523-551 with roll/partition/reverse (:987-1013) and the
  * shift mask (:954-972) folded into the indexing.  qkv: [B*hw*hw, 3C] (q|k|v), heads of 32.    */
-/* lse (optional, fp32 [tokens, heads]): log-sum-exp of every softmax row, saved for the fast backward            */
+/* lse (optional, fp32 [tokens, heads]): log-sum-exp of every softmax row, saved for the fast backward.
+ * mode 2 (fp32 storage only): split-precision products on the matrix cores (attn_split.hip), 1e-6 of the fp32 result */
 int wm_winattn_fwd(const void* qkv, const float* bias_table, void* out, float* lse, int32_t io_bf16, int32_t B,
                    int32_t hw, int32_t C, int32_t shift, int32_t mode, void* stream);
 /* out / lse: the forward's results; when both are given in mode 1 with bf16 storage the register-resident backward
- * is used, otherwise (NULL, fp32 storage or mode 0) scores are re-normalised through LDS.
+ * is used (mode 2 with fp32 storage: its split-precision form), otherwise (NULL, or mode 0) scores are re-normalised through LDS.
  * scratch (optional, device, >= wm_winattn_bwd_scratch_floats() floats, contents irrelevant): per-workgroup partial
  * sums of the relative-position-bias gradient, reduced by a second kernel; NULL = global atomics (slower).        */
 int64_t wm_winattn_bwd_scratch_floats(void);
