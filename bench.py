@@ -241,7 +241,8 @@ def cpu_baseline(attacked, batch=4, steps=3, threads=None, budget_s=None):
             break
     med = statistics.median(times)
     return {"value": batch * TILE_SECONDS / med, "unit": "audio-sec/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{steps} timed steps (1 warm-up) of B={batch} tiles, " if steps else f"the single first step (no warm-up: it exceeded the {budget_s:.0f} s budget) of B={batch} tiles, "
+            "kind": "port", "sample": (f"{steps} timed steps (1 warm-up) of B={batch} tiles, " if steps else
+                       f"the single first step (no warm-up: it exceeded the {budget_s:.0f} s budget) of B={batch} tiles, ") +
                                       f"{'full attack stack' if attacked else 'Identity attack'}, fp32, train mode, AdamW; "
                                       f"median {med:.3f} s/step", "host_cpus": os.cpu_count()}
 
