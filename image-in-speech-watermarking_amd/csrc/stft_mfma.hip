@@ -95,97 +95,122 @@ __device__ __forceinline__ void mma3(f32x16& acc, const bf16x8& th, const bf16x8
 // ------------------------------------------------------------------------------------------------------------------
 // ADJ = false : wave = istft(spec)        frames weighted (1 | 2) / 255, overlap-add, / envelope, centre trim
 // ADJ = true  : dwave = stft^T(dspec)     unweighted overlap-add, reflect padding folded back onto the samples
-// grid (5, B): workgroup j owns OLA slots [28 j, 28 j + 28) (slot s = positions [63 s, 63 s + 63)) and computes the 32
-// frames [28 j - 4, 28 j + 28) that reach them, so no sum crosses a workgroup (frames outside [0, 128) are zero).
+// Work item (tile, j): OLA slots [28 j, 28 j + 28) (slot s = positions [63 s, 63 s + 63)) and the 32 frames [28 j - 4, 28 j + 28)
+// that reach them, so no sum crosses an item (frames outside [0, 128) are zero); five items per tile.
+// Persistent workgroups (round 3): a wave keeps the table fragments of its 32 output rows for all eight k steps in 128
+// registers and walks a strided list of items, the next item's spectrum columns in flight during the products.  Before, a
+// workgroup fetched a k step's fragments from L2 one step ahead of their use — eight dependent round trips that made up most of
+// its 20 us life, and 1280 such workgroups met 1024 resident slots at B = 256.
 template <bool ADJ>
-__global__ __launch_bounds__(256) void synth_mfma_kernel(const float* __restrict__ spec, float* __restrict__ wave,
-                                                         const __bf16* __restrict__ tab, int B) {
+__global__ __launch_bounds__(256, 2) void synth_mfma_kernel(const float* __restrict__ spec, float* __restrict__ wave,
+                                                            const __bf16* __restrict__ tab, int B, int nitems) {
   __shared__ __attribute__((aligned(16))) char smem[FT * LDF * 4 + (ADJ ? SLOTS * HOP * 4 : 0)];
   __bf16* Xs = reinterpret_cast<__bf16*>(smem);               // [re|im][hi|lo][128 k][32 f] bf16 = 32 KB
   float* Fs = reinterpret_cast<float*>(smem);                 // [32 f][257] floats, after the products (aliases Xs)
-  float* Ob = reinterpret_cast<float*>(smem + FT * LDF * 4);  // ADJ: this workgroup's padded-domain sums
-  // Blocks are dealt round-robin to the 8 XCDs.  The 32-frame windows of a tile's five workgroups start at frame 28 j - 4:
-  // their 128-byte row segments straddle two cache lines each, and on five different L2s every line was fetched from
-  // HBM twice (PMC: 2.04 x the spectrum).  Linear id -> (tile, group) so that the groups of one tile share an XCD.
-  const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3, grp = sq % SYN_GROUPS, b = (sq / SYN_GROUPS) * 8 + xcd;
-  if (b >= B) return;
+  float* Ob = reinterpret_cast<float*>(smem + FT * LDF * 4);  // ADJ: this item's padded-domain sums
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int s0 = SLOTS * grp, tf0 = s0 - 4;                   // first slot / first frame (a multiple of 4, may be -4)
-  const float* src = spec + (int64_t)b * 2 * NBIN * NFRAME;
-  // stage the 256 (plane, bin) rows x 32 frames: 8 float4 loads per thread, all issued before the first use
+  TabFrags tb[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) tb[ks] = load_tab(tab, w, ks, lane);
+  // Blocks are dealt round-robin to the 8 XCDs.  The 32-frame windows of a tile's five items start at frame 28 j - 4: their
+  // 128-byte row segments straddle two cache lines each, and on five different L2s every line was fetched from HBM twice
+  // (PMC: 2.04 x the spectrum).  Item id -> (tile, group) so that the groups of one tile share an XCD (the grid is a multiple of
+  // 8, so an item's id mod 8 is its workgroup's XCD).
+  auto tile_of = [&](int item, int& b, int& grp) {
+    const int xcd = item & 7, sq = item >> 3;
+    grp = sq % SYN_GROUPS;
+    b = (sq / SYN_GROUPS) * 8 + xcd;
+  };
+  // the 256 (plane, bin) rows x 32 frames of an item: 8 float4 loads per thread, all issued before the first use
   float4 v[8];
+  auto fetch = [&](int item) {
+    int b, grp;
+    tile_of(item, b, grp);
+    const int tf0 = SLOTS * grp - 4;
+    const float* src = spec + (int64_t)(b < B ? b : 0) * 2 * NBIN * NFRAME;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int id = tid + 256 * q, row = id >> 3, t = tf0 + 4 * (id & 7);
-    v[q] = (t >= 0 && t < NFRAME) ? *reinterpret_cast<const float4*>(src + row * NFRAME + t) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int id = tid + 256 * q, row = id >> 3, k = row & (NBIN - 1), c4 = 4 * (id & 7);
-    const float sc = ADJ ? 1.0f : (k == 0 ? 1.0f : 2.0f) / (float)NFFT;
-    const float e[4] = {v[q].x * sc, v[q].y * sc, v[q].z * sc, v[q].w * sc};
-    bf16x4 hi, lo;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { __bf16 h_, l_; split_bf16(e[u], h_, l_); hi[u] = h_; lo[u] = l_; }
-    __bf16* dst = Xs + ((row >> 7) * 2) * (NBIN * FT) + k * FT + c4;
-    *reinterpret_cast<bf16x4*>(dst) = hi;
-    *reinterpret_cast<bf16x4*>(dst + NBIN * FT) = lo;
-  }
-  __syncthreads();
-  // wave w: output samples n in [32 w, 32 w + 32) of the folded half, all 32 frames
-  f32x16 E, O;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) { E[e] = 0.f; O[e] = 0.f; }
-  TabFrags tb = load_tab(tab, w, 0, lane);
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    TabFrags nx = tb;
-    if (ks + 1 < 8) nx = load_tab(tab, w, ks + 1, lane);
-    const bf16x8 rh = tr_frag32(Xs + 0 * NBIN * FT, ks, lane), rl = tr_frag32(Xs + 1 * NBIN * FT, ks, lane);
-    const bf16x8 ih = tr_frag32(Xs + 2 * NBIN * FT, ks, lane), il = tr_frag32(Xs + 3 * NBIN * FT, ks, lane);
-    mma3(E, tb.ch, tb.cl, rh, rl);
-    mma3(O, tb.sh, tb.sl, ih, il);
-    tb = nx;
-  }
-  __syncthreads();                                            // every wave is done with Xs: the frame image takes its place
-  {
-    const int f = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int n = 32 * w + mma32_row(e, h);
-      Fs[f * LDF + n] = E[e] - O[e];
-      if (n >= 1) Fs[f * LDF + NFFT - n] = E[e] + O[e];
+    for (int q = 0; q < 8; ++q) {
+      const int id = tid + 256 * q, row = id >> 3, t = tf0 + 4 * (id & 7);
+      v[q] = (t >= 0 && t < NFRAME) ? *reinterpret_cast<const float4*>(src + row * NFRAME + t) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-  }
-  __syncthreads();
-  float* dst = wave + (int64_t)b * WLEN;
-  for (int ql = tid; ql < SLOTS * HOP; ql += 256) {
-    const int q = HOP * s0 + ql;
-    float sum = 0.f;
-    if (q < OLA_LEN) {
-      const int s = q / HOP, r = q - HOP * s;
+  };
+  int item = blockIdx.x;
+  if (item < nitems) fetch(item);
+  for (; item < nitems; item += gridDim.x) {
+    int b, grp;
+    tile_of(item, b, grp);
+    const int s0 = SLOTS * grp;                               // first slot; first frame s0 - 4 (a multiple of 4, may be -4)
+    __syncthreads();                                          // the previous item's frame image has been read
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int id = tid + 256 * q, row = id >> 3, k = row & (NBIN - 1), c4 = 4 * (id & 7);
+      const float sc = ADJ ? 1.0f : (k == 0 ? 1.0f : 2.0f) / (float)NFFT;
+      const float e[4] = {v[q].x * sc, v[q].y * sc, v[q].z * sc, v[q].w * sc};
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { __bf16 h_, l_; split_bf16(e[u], h_, l_); hi[u] = h_; lo[u] = l_; }
+      __bf16* dst = Xs + ((row >> 7) * 2) * (NBIN * FT) + k * FT + c4;
+      *reinterpret_cast<bf16x4*>(dst) = hi;
+      *reinterpret_cast<bf16x4*>(dst + NBIN * FT) = lo;
+    }
+    __syncthreads();
+    if (item + (int)gridDim.x < nitems) fetch(item + gridDim.x);   // next item: in flight during the products and the overlap-add
+    if (b >= B) continue;                                     // (padding item of a batch that is no multiple of 8; uniform)
+    // wave w: output samples n in [32 w, 32 w + 32) of the folded half, all 32 frames
+    f32x16 E, O;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { E[e] = 0.f; O[e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 rh = tr_frag32(Xs + 0 * NBIN * FT, ks, lane), rl = tr_frag32(Xs + 1 * NBIN * FT, ks, lane);
+      const bf16x8 ih = tr_frag32(Xs + 2 * NBIN * FT, ks, lane), il = tr_frag32(Xs + 3 * NBIN * FT, ks, lane);
+      mma3(E, tb[ks].ch, tb[ks].cl, rh, rl);
+      mma3(O, tb[ks].sh, tb[ks].sl, ih, il);
+    }
+    __syncthreads();                                          // every wave is done with Xs: the frame image takes its place
+    {
+      const int f = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = 32 * w + mma32_row(e, h);
+        Fs[f * LDF + n] = E[e] - O[e];
+        if (n >= 1) Fs[f * LDF + NFFT - n] = E[e] + O[e];
+      }
+    }
+    __syncthreads();
+    float* dst = wave + (int64_t)b * WLEN;
+    // overlap-add: five frames reach a position (frames outside [0, 128) hold zeros); the five reads are issued unconditionally
+    // at clamped addresses (a read under a branch waits for the one before it: 35 dependent LDS round trips per thread)
+    for (int ql = tid; ql < SLOTS * HOP; ql += 256) {
+      const int q = HOP * s0 + ql;
+      const int sl = ql / HOP, r = ql - HOP * sl;             // slot within the item, position within the slot
+      float t5[5];
 #pragma unroll
       for (int jj = 0; jj < 5; ++jj) {
-        const int t = s - jj, m = HOP * jj + r;
-        if (m < NFFT && t >= 0 && t < NFRAME) sum += Fs[(t - tf0) * LDF + m];
+        const int m = HOP * jj + r;
+        t5[jj] = Fs[(sl + 4 - jj) * LDF + (m < NFFT ? m : 0)];
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 5; ++jj) sum += (HOP * jj + r < NFFT) ? t5[jj] : 0.f;
+      if (q >= OLA_LEN) sum = 0.f;
+      if (ADJ) {
+        Ob[ql] = sum;
+      } else {
+        const int i = q - PADL;
+        if (i >= 0 && i < WLEN) dst[i] = sum / (float)frames_covering(q);
       }
     }
     if (ADJ) {
-      Ob[ql] = sum;
-    } else {
-      const int i = q - PADL;
-      if (i >= 0 && i < WLEN) dst[i] = sum / (float)frames_covering(q);
-    }
-  }
-  if (ADJ) {
-    __syncthreads();
-    for (int ql = tid; ql < SLOTS * HOP; ql += 256) {
-      const int i = HOP * s0 + ql - PADL;
-      if (i < 0 || i >= WLEN) continue;
-      float val = Ob[ql];
-      if (i >= 1 && i <= PADL) val += Ob[PADL - i - HOP * s0];                       // left reflection (workgroup 0 holds both)
-      if (i >= WLEN - 1 - PADL && i <= WLEN - 2) val += Ob[2 * (WLEN - 1) - i + PADL - HOP * s0];   // right (workgroup 4)
-      dst[i] = val;
+      __syncthreads();
+      for (int ql = tid; ql < SLOTS * HOP; ql += 256) {
+        const int i = HOP * s0 + ql - PADL;
+        if (i < 0 || i >= WLEN) continue;
+        float val = Ob[ql];
+        if (i >= 1 && i <= PADL) val += Ob[PADL - i - HOP * s0];                       // left reflection (item 0 holds both)
+        if (i >= WLEN - 1 - PADL && i <= WLEN - 2) val += Ob[2 * (WLEN - 1) - i + PADL - HOP * s0];   // right (item 4)
+        dst[i] = val;
+      }
     }
   }
 }
@@ -193,92 +218,123 @@ __global__ __launch_bounds__(256) void synth_mfma_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------------------------
 // ADJ = false : spec = stft(wave)          reflect padding
 // ADJ = true  : dspec = istft^T(dwave)     zero padding, 1 / envelope on the samples, (1 | 2) / 255 on the bins
-// grid (4, B): workgroup = 32 frames x 128 bins x (re, im); wave w owns bins [32 w, 32 w + 32).
+// Work item = 32 frames x 128 bins x (re, im) of one tile (four per tile); wave w owns bins [32 w, 32 w + 32).  Persistent
+// workgroups with the table fragments in registers and the next item's samples in flight, as in synth_mfma_kernel.
 template <bool ADJ>
-__global__ __launch_bounds__(256) void analysis_mfma_kernel(const float* __restrict__ wave, float* __restrict__ spec,
-                                                            const __bf16* __restrict__ tab) {
-  __shared__ __attribute__((aligned(16))) float xs[SPAN + 8];
+__global__ __launch_bounds__(256, 2) void analysis_mfma_kernel(const float* __restrict__ wave, float* __restrict__ spec,
+                                                               const __bf16* __restrict__ tab, int nitems) {
+  __shared__ __attribute__((aligned(16))) float xs[2][SPAN + 8];             // this item's samples | the next item's
   __shared__ __attribute__((aligned(16))) __bf16 UV[4 * FT * LDU];          // [u|v][hi|lo][32 t][136]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.y, t0 = FT * blockIdx.x;
-  const float* src = wave + (int64_t)b * WLEN;
-  for (int s = tid; s < SPAN; s += 256) {
-    const int q = HOP * t0 + s;                               // padded / overlap-add coordinate
-    int i = q - PADL;
-    float val;
-    if (ADJ) {
-      val = (i >= 0 && i < WLEN) ? src[i] / (float)frames_covering(q) : 0.f;
-    } else {
-      if (i < 0) i = -i;
-      if (i >= WLEN) i = 2 * (WLEN - 1) - i;
-      val = src[i];
-    }
-    xs[s] = val;
-  }
-  __syncthreads();
-  // folded frames u[n] = x[n] + x[255 - n], v[n] = x[n] - x[255 - n] (u[0] = x[0], v[0] = 0), split, [t][n] images.
-  // lane -> frame (stride 63 words between lanes: conflict-free reads), wave / half-wave -> two chunks of 8 samples.
-  // NOTE (measured, MI355X / ROCm 7.2): with SLP vectorisation on, the folds below compile to v_pk_add_f32 on register
-  // pairs that ds_read2_b32 has just delivered, and with a second workgroup resident on the CU the SUM (not the
-  // difference, computed a few instructions earlier from the same registers) came out wrong in lanes 48-63 of the last
-  // chunk about once per 5 launches at B = 96.  This file is therefore built with -fno-slp-vectorize (csrc/Makefile);
-  // tests/test_kernels_gpu.py::test_stft_round_trip_is_deterministic_under_load holds it.
-  {
-    const int t = tid & 31, c0 = tid >> 5;
-    const float* fr = xs + HOP * t;
-    float a[2][8], m[2][8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  TabFrags tb[8];
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+  for (int ks = 0; ks < 8; ++ks) tb[ks] = load_tab(tab, w, ks, lane);
+  constexpr int NPV = (SPAN + 255) / 256;                      // 9 samples per thread
+  float pv[NPV];
+  auto fetch = [&](int item) {
+    const int b = item >> 2, t0 = FT * (item & 3);
+    const float* src = wave + (int64_t)b * WLEN;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int n = 8 * (c0 + 8 * it) + j;
-        a[it][j] = fr[n];
-        m[it][j] = fr[n ? NFFT - n : 0];
+    for (int u = 0; u < NPV; ++u) {
+      const int s = tid + 256 * u;
+      const int q = HOP * t0 + (s < SPAN ? s : SPAN - 1);       // padded / overlap-add coordinate
+      int i = q - PADL;
+      float val;
+      if (ADJ) {
+        val = (i >= 0 && i < WLEN) ? src[i] / (float)frames_covering(q) : 0.f;
+      } else {
+        if (i < 0) i = -i;
+        if (i >= WLEN) i = 2 * (WLEN - 1) - i;
+        val = src[i];
       }
+      pv[u] = val;
+    }
+  };
+  auto stage = [&](float* buf) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int n0 = 8 * (c0 + 8 * it);
-      bf16x8 uh, ul, vh, vl;
+    for (int u = 0; u < NPV; ++u) {
+      const int s = tid + 256 * u;
+      if (s < SPAN) buf[s] = pv[u];
+    }
+  };
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  fetch(item);
+  stage(xs[0]);
+  int cur = 0;
+  // (the NEXT item's samples are staged before this item's 32 stores per lane are issued: see synth_mfma_kernel)
+  for (; item < nitems; item += gridDim.x, cur ^= 1) {
+    const int b = item >> 2, t0 = FT * (item & 3);
+    const bool more = item + (int)gridDim.x < nitems;
+    __syncthreads();                                          // the samples are staged; the previous item's folded frames consumed
+    if (more) fetch(item + gridDim.x);
+    // folded frames u[n] = x[n] + x[255 - n], v[n] = x[n] - x[255 - n] (u[0] = x[0], v[0] = 0), split, [t][n] images.
+    // lane -> frame (stride 63 words between lanes: conflict-free reads), wave / half-wave -> two chunks of 8 samples.
+    // NOTE (measured, MI355X / ROCm 7.2): with SLP vectorisation on, the folds below compile to v_pk_add_f32 with a
+    // half-crossing operand selector, which returns wrong values in lanes 16-31 / 48-63 (scripts/experiments/
+    // fold_hazard).  The library is built with -fno-slp-vectorize and scripts/check_isa.py rejects the form;
+    // tests/test_kernels_gpu.py::test_stft_round_trip_is_deterministic_under_load holds it.
+    {
+      const int t = tid & 31, c0 = tid >> 5;
+      const float* fr = xs[cur] + HOP * t;
+      float a[2][8], m[2][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const bool dc = n0 + j == 0;
-        __bf16 h_, l_;
-        split_bf16(dc ? a[it][j] : a[it][j] + m[it][j], h_, l_); uh[j] = h_; ul[j] = l_;
-        split_bf16(dc ? 0.f : a[it][j] - m[it][j], h_, l_); vh[j] = h_; vl[j] = l_;
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int n = 8 * (c0 + 8 * it) + j;
+          a[it][j] = fr[n];
+          m[it][j] = fr[n ? NFFT - n : 0];
+        }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int n0 = 8 * (c0 + 8 * it);
+        bf16x8 uh, ul, vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool dc = n0 + j == 0;
+          __bf16 h_, l_;
+          split_bf16(dc ? a[it][j] : a[it][j] + m[it][j], h_, l_); uh[j] = h_; ul[j] = l_;
+          split_bf16(dc ? 0.f : a[it][j] - m[it][j], h_, l_); vh[j] = h_; vl[j] = l_;
+        }
+        __bf16* d = UV + t * LDU + n0;
+        *reinterpret_cast<bf16x8*>(d) = uh;
+        *reinterpret_cast<bf16x8*>(d + FT * LDU) = ul;
+        *reinterpret_cast<bf16x8*>(d + 2 * FT * LDU) = vh;
+        *reinterpret_cast<bf16x8*>(d + 3 * FT * LDU) = vl;
       }
-      __bf16* d = UV + t * LDU + n0;
-      *reinterpret_cast<bf16x8*>(d) = uh;
-      *reinterpret_cast<bf16x8*>(d + FT * LDU) = ul;
-      *reinterpret_cast<bf16x8*>(d + 2 * FT * LDU) = vh;
-      *reinterpret_cast<bf16x8*>(d + 3 * FT * LDU) = vl;
+    }
+    __syncthreads();
+    f32x16 RE, IM;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { RE[e] = 0.f; IM[e] = 0.f; }
+    const int r = lane & 31, h = lane >> 5;
+    const __bf16* brow = UV + r * LDU + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 uh = *reinterpret_cast<const bf16x8*>(brow + 16 * ks);
+      const bf16x8 ul = *reinterpret_cast<const bf16x8*>(brow + 16 * ks + FT * LDU);
+      const bf16x8 vh = *reinterpret_cast<const bf16x8*>(brow + 16 * ks + 2 * FT * LDU);
+      const bf16x8 vl = *reinterpret_cast<const bf16x8*>(brow + 16 * ks + 3 * FT * LDU);
+      mma3(RE, tb[ks].ch, tb[ks].cl, uh, ul);
+      mma3(IM, tb[ks].sh, tb[ks].sl, vh, vl);
+    }
+    if (more) stage(xs[cur ^ 1]);                             // (the other buffer: its reader, the previous fold, is long done)
+    float* dst = spec + (int64_t)b * 2 * NBIN * NFRAME + t0 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = 32 * w + mma32_row(e, h);
+      const float wk = ADJ ? (k == 0 ? 1.0f : 2.0f) / (float)NFFT : 1.0f;
+      __builtin_nontemporal_store(RE[e] * wk, dst + k * NFRAME);
+      __builtin_nontemporal_store((ADJ && k == 0) ? 0.f : -IM[e] * wk, dst + (NBIN + k) * NFRAME);
     }
   }
-  __syncthreads();
-  f32x16 RE, IM;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) { RE[e] = 0.f; IM[e] = 0.f; }
-  const int r = lane & 31, h = lane >> 5;
-  const __bf16* brow = UV + r * LDU + 8 * h;
-  TabFrags tb = load_tab(tab, w, 0, lane);
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    TabFrags nx = tb;
-    if (ks + 1 < 8) nx = load_tab(tab, w, ks + 1, lane);
-    const bf16x8 uh = *reinterpret_cast<const bf16x8*>(brow + 16 * ks);
-    const bf16x8 ul = *reinterpret_cast<const bf16x8*>(brow + 16 * ks + FT * LDU);
-    const bf16x8 vh = *reinterpret_cast<const bf16x8*>(brow + 16 * ks + 2 * FT * LDU);
-    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(brow + 16 * ks + 3 * FT * LDU);
-    mma3(RE, tb.ch, tb.cl, uh, ul);
-    mma3(IM, tb.sh, tb.sl, vh, vl);
-    tb = nx;
-  }
-  float* dst = spec + (int64_t)b * 2 * NBIN * NFRAME + t0 + r;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int k = 32 * w + mma32_row(e, h);
-    const float wk = ADJ ? (k == 0 ? 1.0f : 2.0f) / (float)NFFT : 1.0f;
-    dst[k * NFRAME] = RE[e] * wk;
-    dst[(NBIN + k) * NFRAME] = (ADJ && k == 0) ? 0.f : -IM[e] * wk;
-  }
+}
+
+// persistent grids: two 256-thread workgroups per CU (tables in registers: 2 waves per SIMD), a multiple of 8 (XCD affinity)
+inline int persistent_grid(int nitems) {
+  int g = nitems < 512 ? nitems : 512;
+  return (g + 7) / 8 * 8;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -297,29 +353,33 @@ extern "C" int wm_stft255_tables(void* tables, void* stream) {
 
 extern "C" int wm_istft255_fwd(const float* spec, float* wave, const void* tables, int32_t B, void* stream) {
   if (!spec || !wave || !tables || B <= 0 || !aligned16(spec) || !aligned16(tables)) return WM_EINVAL;
-  hipLaunchKernelGGL(synth_mfma_kernel<false>, dim3(8 * ((B + 7) / 8) * SYN_GROUPS), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     spec, wave, static_cast<const __bf16*>(tables), B);
+  const int nitems = 8 * ((B + 7) / 8) * SYN_GROUPS;
+  hipLaunchKernelGGL(synth_mfma_kernel<false>, dim3(persistent_grid(nitems)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     spec, wave, static_cast<const __bf16*>(tables), B, nitems);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
 extern "C" int wm_stft255_bwd(const float* dspec, float* dwave, const void* tables, int32_t B, void* stream) {
   if (!dspec || !dwave || !tables || B <= 0 || !aligned16(dspec) || !aligned16(tables)) return WM_EINVAL;
-  hipLaunchKernelGGL(synth_mfma_kernel<true>, dim3(8 * ((B + 7) / 8) * SYN_GROUPS), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     dspec, dwave, static_cast<const __bf16*>(tables), B);
+  const int nitems = 8 * ((B + 7) / 8) * SYN_GROUPS;
+  hipLaunchKernelGGL(synth_mfma_kernel<true>, dim3(persistent_grid(nitems)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dspec, dwave, static_cast<const __bf16*>(tables), B, nitems);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
 extern "C" int wm_stft255_fwd(const float* wave, float* spec, const void* tables, int32_t B, void* stream) {
   if (!wave || !spec || !tables || B <= 0 || !aligned16(tables)) return WM_EINVAL;
-  hipLaunchKernelGGL(analysis_mfma_kernel<false>, dim3(NFRAME / FT, B), dim3(256), 0, static_cast<hipStream_t>(stream), wave,
-                     spec, static_cast<const __bf16*>(tables));
+  const int nitems = (NFRAME / FT) * B;
+  hipLaunchKernelGGL(analysis_mfma_kernel<false>, dim3(persistent_grid(nitems)), dim3(256), 0, static_cast<hipStream_t>(stream), wave,
+                     spec, static_cast<const __bf16*>(tables), nitems);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
 extern "C" int wm_istft255_bwd(const float* dwave, float* dspec, const void* tables, int32_t B, void* stream) {
   if (!dwave || !dspec || !tables || B <= 0 || !aligned16(tables)) return WM_EINVAL;
-  hipLaunchKernelGGL(analysis_mfma_kernel<true>, dim3(NFRAME / FT, B), dim3(256), 0, static_cast<hipStream_t>(stream), dwave,
-                     dspec, static_cast<const __bf16*>(tables));
+  const int nitems = (NFRAME / FT) * B;
+  hipLaunchKernelGGL(analysis_mfma_kernel<true>, dim3(persistent_grid(nitems)), dim3(256), 0, static_cast<hipStream_t>(stream), dwave,
+                     dspec, static_cast<const __bf16*>(tables), nitems);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
