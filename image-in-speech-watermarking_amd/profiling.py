@@ -41,7 +41,8 @@ COST = {
     "dwconv_fwd": lambda h1, w, b, h2, B, hw, Ch, a2=None, g2=None: (18.0 * B * hw * hw * Ch, (1.0 + sum(t is not None for t in (h2, a2, g2))) * h1.element_size() * B * hw * hw * Ch),
     "dwconv_bwd": lambda h1, d, w, dh, dw, db, B, hw, Ch, scratch=None, defer=None: (54.0 * B * hw * hw * Ch, 3.0 * h1.element_size() * B * hw * hw * Ch),
     "layernorm_fwd": lambda x, g, b, m, y, *a: (8.0 * x.numel(), (4.0 + y.element_size()) * x.numel()),
-    "layernorm_bwd": lambda dy, x, *a, **k: (16.0 * x.numel(), (12.0 + dy.element_size()) * x.numel()),
+    # dy, x and the residual gradient read, dx written (+ its bf16 copy for the next GEMM when asked for)
+    "layernorm_bwd": lambda dy, x, *a, **k: (16.0 * x.numel(), (12.0 + dy.element_size() + (2.0 if k.get("dx_bf16") is not None else 0.0)) * x.numel()),
     "im2col": lambda x, cols, *a: (0.0, 4.0 * (x.numel() + cols.numel())),
     "col2im": lambda dc, dx, *a: (0.0, 4.0 * (dx.numel() + dc.numel())),
     "pixel_shuffle": lambda y4, *a: (0.0, 8.0 * y4.numel()),
