@@ -33,6 +33,15 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(const JobTable t) {
   const float* p = jb.src + (int64_t)p0 * jb.pstride + (int64_t)r * jb.src_ld + c;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int q = p0;
+  // a thread's partials are `pstride` apart: every load is its own memory round trip, so the launch lasts (partials per thread /
+  // loads in flight) round trips.  Sixteen in flight: the 64-slice weight gradients of the wide layers took 16 trips with four.
+  for (; q + 16 <= p1; q += 16, p += 16 * jb.pstride) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[u * jb.pstride];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+  }
   for (; q + 4 <= p1; q += 4, p += 4 * jb.pstride) {          // four partials in flight
     s0 += p[0];
     s1 += p[jb.pstride];
