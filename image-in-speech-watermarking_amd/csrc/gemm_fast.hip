@@ -17,6 +17,9 @@
 namespace {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+#ifndef NT_SMALL_BK
+#define NT_SMALL_BK 128
+#endif
 #ifndef NT_NBUF
 #define NT_NBUF 1
 #endif
@@ -311,9 +314,12 @@ __device__ __forceinline__ void epi_interior(const float* cs, const WmGemm& g, i
 // bf16 x bf16 instances are held to 168 registers per lane (3 waves per SIMD = 3 workgroups per CU); they need 172 unconstrained
 // SPLIT (compute_mode "split", fp32 operands): every operand tile is staged as a high and a low bf16 image (x = hi + lo) and a
 // product is three MFMAs, hi*hi + hi*lo + lo*hi: 2^-17 relative per term at 3/16 of the fp32-MFMA time (the round-2 STFT trick)
-template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int EPI, bool SPLIT = false>
+// BKT: k depth of a staged tile.  64 everywhere but in the 64 x 64-tile instances, which run where a launch has about one
+// workgroup per CU (the deep levels at small batches): nothing overlaps their load -> LDS -> MFMA chain there, an iteration lasts one
+// memory round trip whatever it carries, so they carry 128.
+template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int EPI, bool SPLIT = false, int BKT = 64>
 __global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 && EPI != 4 ? 3 : 2)) void gemm_nt_kernel(const WmGemm g, const bool vec_ok, const int tiles_n, const int tiles_m) {
-  constexpr int BK = 64, BM = WM * TM * 32, BN = WN * TN * 32, LDA = BK + 8;
+  constexpr int BK = BKT, BM = WM * TM * 32, BN = WN * TN * 32, LDA = BK + 8;
   constexpr int LDB = B_TR ? BN + 32 : BK + 8, BSZ1 = B_TR ? BK * LDB : BN * LDB;
   constexpr int ASZ = (SPLIT ? 2 : 1) * BM * LDA, BSZ = (SPLIT ? 2 : 1) * BSZ1;
   constexpr int NBUF = NT_NBUF;                              // LDS operand buffers (1: more workgroups per CU, one more barrier per k tile)
@@ -711,22 +717,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int 
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int EPI, bool SPLIT = false>
+template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int EPI, bool SPLIT = false, int BKT = 64>
 int launch_nt_epi(const WmGemm& g, bool vec_ok, hipStream_t st) {
-  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = BKT;
   constexpr size_t bsz = B_TR ? BK * (BN + 32) : BN * (BK + 8);
   constexpr size_t stage = (SPLIT ? 2 : 1) * NT_NBUF * 2 * (BM * (BK + 8) + bsz), ctile = sizeof(float) * TM * 32 * (BN + 4);
   constexpr size_t smem = stage > ctile ? stage : ctile;
   static bool attr = false;
   if (!attr) {
     if (smem > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, EPI, SPLIT>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, EPI, SPLIT, BKT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   wm_gemm_family_tls = WM_FAM_NT;
-  hipLaunchKernelGGL((gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, EPI, SPLIT>), dim3(8 * ((tiles_m + 7) / 8) * tiles_n), dim3(256),
+  hipLaunchKernelGGL((gemm_nt_kernel<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, EPI, SPLIT, BKT>), dim3(8 * ((tiles_m + 7) / 8) * tiles_n), dim3(256),
                      smem, st, g, vec_ok, tiles_n, tiles_m);
   WM_CHECK_LAUNCH();
   return WM_OK;
@@ -746,7 +752,7 @@ int dispatch_nt_split(const WmGemm& g, hipStream_t st) {
 }
 
 // picks the epilogue specialisation from the operands that are present (3 = general code)
-template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN>
+template <typename AT, typename BT, bool B_TR, bool A_GELU, int WM, int WN, int TM, int TN, int BKT = 64>
 int launch_nt(const WmGemm& g, hipStream_t st) {
   constexpr int BM = WM * TM * 32;
   const bool vec_ok = al16(g.C) && !(g.ldc & 7) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && !(g.ldr & 3))) &&
@@ -758,18 +764,18 @@ int launch_nt(const WmGemm& g, hipStream_t st) {
       if (!(vec_ok && sc_ok) || g.c_bf16 || !g.res || g.gaux || g.N != BN || (g.M % BM) || !al16(g.ln_gamma) || !al16(g.ln_beta) ||
           !al16(g.ln_out) || (g.ln_mod && (!al16(g.ln_mod) || g.ln_hw <= 0 || ((int64_t)g.ln_hw * g.ln_hw) % BM)))
         return WM_EINVAL;
-      return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 4>(g, vec_ok, st);
+      return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 4, false, BKT>(g, vec_ok, st);
     } else {
       return WM_EINVAL;
     }
   }
   if (vec_ok && sc_ok) {
-    if (g.c_bf16 && !g.gaux && !g.res) return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 0>(g, vec_ok, st);
-    if (!g.c_bf16 && g.res && !g.gaux) return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 1>(g, vec_ok, st);
+    if (g.c_bf16 && !g.gaux && !g.res) return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 0, false, BKT>(g, vec_ok, st);
+    if (!g.c_bf16 && g.res && !g.gaux) return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 1, false, BKT>(g, vec_ok, st);
     if (g.c_bf16 && g.gaux && g.gaux_raw && g.gaux_bf16 && !g.res && !g.bias)
-      return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 2>(g, vec_ok, st);
+      return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 2, false, BKT>(g, vec_ok, st);
   }
-  return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 3>(g, vec_ok, st);
+  return launch_nt_epi<AT, BT, B_TR, A_GELU, WM, WN, TM, TN, 3, false, BKT>(g, vec_ok, st);
 }
 
 template <typename AT, typename BT, bool B_TR, bool A_GELU>
@@ -788,7 +794,7 @@ int dispatch_nt(const WmGemm& g, hipStream_t st) {
   if (g.N == 192 && t12864 >= 384) return launch_nt<AT, BT, B_TR, A_GELU, 2, 2, 2, 1>(g, st);
   if (g.N > 64 && t128 >= 384) return launch_nt<AT, BT, B_TR, A_GELU, 2, 2, 2, 2>(g, st);   // 128 x 128
   if (t12864 >= 384 || g.M >= 32768) return launch_nt<AT, BT, B_TR, A_GELU, 2, 2, 2, 1>(g, st);  // 128 x 64
-  return launch_nt<AT, BT, B_TR, A_GELU, 2, 2, 1, 1>(g, st);                           // 64 x 64
+  return launch_nt<AT, BT, B_TR, A_GELU, 2, 2, 1, 1, NT_SMALL_BK>(g, st);              // 64 x 64, 128 deep
 }
 
 // C[m][n] += sum over z in this block's segment of part[z][m][n]; thread = 4 consecutive n (N % 4 == 0)
