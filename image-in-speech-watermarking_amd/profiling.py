@@ -193,12 +193,15 @@ def time_stft_path(wm, batch, attack_cfg, reps=20):
                 fn()
         g.replay()
         torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        g.replay()
-        e.record()
-        torch.cuda.synchronize()
-        res[name] = s.elapsed_time(e) / reps * 1e-3                     # seconds per launch
+        times = []
+        for _ in range(5):                                               # median of five replays: one replay can catch a hiccup
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            g.replay()
+            e.record()
+            torch.cuda.synchronize()
+            times.append(s.elapsed_time(e))
+        res[name] = sorted(times)[2] / reps * 1e-3                      # seconds per launch
     return res
 
 
