@@ -260,3 +260,32 @@ def test_hidden_checkpoint_round_trip_and_layout(wm, tmp_path):
         assert torch.equal(v, w), k
     with pytest.raises(wm.WmKernelError):
         a.encoder_decoder(torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 4, 4))       # CPU tensors are refused, no fallback
+
+
+def test_bench_usable_cores_follows_the_cgroup_quota(monkeypatch):
+    """The all-cores CPU baseline leg (bench.py) sizes itself by what the process may USE: a cgroup CPU quota below the visible
+    physical cores wins over the affinity mask (a 1-GPU box shows 256 CPUs and grants 16)."""
+    import builtins
+    import io
+    import bench
+    monkeypatch.setattr(os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    real_open = builtins.open
+
+    def fake_open(quota):
+        def _open(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                if quota is None:
+                    raise OSError("no cgroup v2")
+                return io.StringIO(quota)
+            if str(path).startswith("/sys/fs/cgroup/cpu/"):
+                raise OSError("no cgroup v1")
+            return real_open(path, *a, **k)
+        return _open
+    monkeypatch.setattr(builtins, "open", fake_open("1600000 100000\n"))
+    n, why = bench.usable_cores()
+    assert n == 16 and "quota" in why
+    monkeypatch.setattr(builtins, "open", fake_open("max 100000\n"))
+    assert bench.usable_cores()[0] == 128                           # SMT pairs of the 256 visible CPUs
+    monkeypatch.setattr(builtins, "open", fake_open(None))
+    assert bench.usable_cores()[0] == 128
