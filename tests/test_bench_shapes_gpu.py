@@ -54,6 +54,9 @@ NT_SHAPES = [
     (6144, 512, 512, "proj C=512: 128x128 at K=512"),
     (6144 + 8, 2048, 512, "fc1 C=512: 128x128, 16 column tiles, ragged M"),
     (1536, 256, 1024, "coarse stage: 64x64 tiles"),
+    (1000, 72, 200, "64x64 tiles, 128-deep k tiles: one full tile + a 72-wide tail, ragged M, column-edge tile"),
+    (520, 64, 72, "64x64 tiles: K below one 128-deep tile"),
+    (2048, 136, 328, "64x64 tiles: two full k tiles + a 72-wide tail, three column tiles"),
 ]
 
 
