@@ -549,6 +549,8 @@ def kernel_rooflines(a, wm, net, opt, attack, extract_from, x, msg, result):
     pmc = prof.find_pmc_summary(os.path.join(ROOT, "profiles"), a.batch, a.mode, a.attack)
     result["roofline"]["traffic"] = prof.pmc_traffic(rows[0]["kernel"], pmc)
     result["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) if pmc else None
+    # whole-step HBM traffic per tile from the same PMC summary (the number the fusion work is judged by)
+    result["hbm_traffic"] = prof.pmc_step_traffic(pmc, a.batch)
     result["roofline_by_kernel"] = [
         {k: (round(v, 4) if isinstance(v, float) else v) for k, v in prof.roofline_of(r).items()
          if k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us")}

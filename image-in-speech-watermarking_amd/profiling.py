@@ -257,6 +257,26 @@ def pmc_traffic(kernel_family, path):
     return tot / launches if launches else None
 
 
+def pmc_step_traffic(path, tiles):
+    """Whole-step HBM traffic from a PMC summary: sum over kernel families of (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches
+    per step (the trace's step count = its adamw_kernel launches), per step and per tile, and the rate over the summed kernel time.
+    None without a summary."""
+    import json
+    import os
+    if not path or not os.path.exists(path):
+        return None
+    fams = json.load(open(path)).get("families", {})
+    steps = fams.get("adamw_kernel", {}).get("launches", 0)
+    if not steps:
+        return None
+    byts = sum((f.get("hbm_bytes_per_launch") or 0.0) * f["launches"] for f in fams.values()) / steps
+    ms = sum(f["total_ms"] for f in fams.values()) / steps
+    return {"GB_per_step": byts / 1e9, "GB_per_tile": byts / 1e9 / max(int(tiles), 1), "kernel_ms_per_step": ms,
+            "TBps_over_kernel_time": byts / (ms * 1e-3) / 1e12 if ms > 0 else None,
+            "launches_per_step": sum(f["launches"] for f in fams.values()) / steps,
+            "formula": "sum over families of (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches / steps in the trace"}
+
+
 def pmc_mfma_util(path):
     """MFMA utilisation from counters (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)) of the MFMA-carrying
     kernel families and of the whole step, as scripts/summarize_rocprof.py wrote them; None without a summary."""
