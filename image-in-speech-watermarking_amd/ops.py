@@ -45,10 +45,11 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=1, b_kc=1, a_op=0, b_op=0, bia
 
 
 def ln_fusable(M, N, K, mode, a_bf16=True):
-    """Can linear_fwd(..., ln=...) produce the LayerNorm of its output rows in the same launch?  (WM_NO_LN_FUSE=1: never — the
-    A/B switch of the benchmarks.)"""
+    """Can linear_fwd(..., ln=...) produce the LayerNorm of its output rows in the same launch?  (WM_NO_LN_FUSE=1: never; a comma
+    list of widths: not at those — the A/B switch of the benchmarks.)"""
     import os
-    if os.environ.get("WM_NO_LN_FUSE") == "1":
+    off = os.environ.get("WM_NO_LN_FUSE", "")
+    if off == "1" or (off and off != "0" and str(N) in off.split(",")):     # "1": never; "32,64": not at these widths
         return False
     return bool(lib.wm_gemm_ln_fusable(M, N, K, mode, int(a_bf16)))
 
