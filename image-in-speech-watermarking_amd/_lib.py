@@ -67,6 +67,10 @@ _SIGS = {
     "wm_dwconv_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_dwconv_bwd_scratch_floats": [c_i32, c_i32, c_i32],
     "wm_dwconv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.POINTER(WmReduceJob), c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_leff_fusable": [c_i32, c_i32],
+    "wm_leff_fwd": [c_f] * 12 + [c_i32, c_i32, c_i32, c_f],
+    "wm_leff_bwd_scratch_floats": [c_i32, c_i32, c_i32],
+    "wm_leff_bwd": [c_f, c_i32] + [c_f] * 11 + [C.POINTER(WmReduceJob), c_i32, c_i32, c_i32, c_f],
     "wm_im2col_4x4s2": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_col2im_4x4s2": [c_f, c_i32, c_f, c_i32, c_i32, c_i32, c_f],
     "wm_pixel_shuffle2": [c_f, c_i32, c_f, c_f, c_i32, c_i32, c_i32, c_i64, c_i32, c_f],

@@ -12,6 +12,7 @@
 //   gemm_tn_kernel   C[M,N] += A[K,M]^T B[K,N] (+ column sums of A): weight gradients, split-K, fp32 atomics
 #include <cstdlib>
 #include "common.h"
+#include "gelu_poly.h"
 #include "../../include/wm_kernels.h"
 
 namespace {
@@ -52,9 +53,12 @@ template <> struct Chunk<__bf16> {
       uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float a = bf_lo(w[j]), b = bf_hi(w[j]);
-        if (GELU) { a = gelu_f(a); b = gelu_f(b); }
-        w[j] = pack_bf2(a * sc, b * sc);
+        f32x2 a = {bf_lo(w[j]), bf_hi(w[j])};
+        if (GELU) {                                          // bf16 in, bf16 out: the packed polynomial form (gelu_poly.h) —
+          f32x2 g;                                           // fc2's weight gradient reads the saved h2 of the fused LeFF this way
+          gelu_pair<__bf16>(a, a, g);
+        }
+        w[j] = pack_bf2(a.x * sc, a.y * sc);
       }
       x = make_uint4(w[0], w[1], w[2], w[3]);
     }

@@ -1,0 +1,622 @@
+// LeFF as two fused kernels for the blocks with C <= 128 (bf16 mode): reference LeFF.forward, model.py:695-714
+//   x -> linear1 -> GELU -> rearrange -> depthwise 3x3 -> GELU -> rearrange -> linear2      (+ DropPath, + residual, :1016-1017)
+// and its autograd backward.  These blocks carry 59 % of the step's token-channels and sit a factor 5-10 below the machine's
+// flop / byte ridge (C / 2 flop per byte), so what they cost is HBM round trips between operators: the un-fused chain moves
+// 50 C bytes per token forward (fc1 10 C, depthwise conv 24 C, fc2 16 C) and 52 C in the two input-gradient products and the
+// depthwise backward.  Here a workgroup keeps an 8 x 8-pixel tile on chip across the three operators:
+//
+//   forward   xn2 halo tile (10 x 10 x C, bf16) -> LDS; per 64-channel slice of the hidden width: fc1 on the matrix cores (hidden
+//             on the accumulator rows, pixel on the lane) -> h1 (saved, centre pixels) -> GELU in place -> depthwise 3 x 3 with the
+//             window sliding in registers -> h2 (saved) -> GELU -> A operand of fc2, whose [64 x C] accumulator stays in registers
+//             over the slices; epilogue (acc + b2) * DropPath + x1.   2 C (x 1.56 halo, mostly L2) + 4 C + 4 C + 16 C saved = 27 C.
+//   backward  dy halo tile -> LDS; per slice: dh2 = (dy W2) * gelu'(h2) * DropPath on the halo (the saved h2 slice is staged in
+//             the buffer the product lands in), transposed depthwise conv * gelu'(h1) -> dh1 (written for the fc1 weight
+//             gradient) -> A operand of dxn2 += dh1 W1; depthwise weight / bias gradients summed in LDS over the strip of tiles
+//             a workgroup walks.  Weights are staged as they lie and read with ds_read_b64_tr_b16 where the product wants
+//             them transposed.  ~30 C instead of 52 C.
+// fc1 / fc2 weight gradients stay on the TN GEMM (K = tokens): fc2's reads the saved h2 with GELU applied while staging.
+#include "common.h"
+#include "gelu_poly.h"
+#include "../../include/wm_kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr int TP = 8;               // tile is TP x TP pixels
+constexpr int HP = TP + 2;          // with halo
+constexpr int NPIX = HP * HP;       // 100 halo pixels (4 MFMA row tiles of 32, the last one mostly padding)
+constexpr int TCH = 64;             // hidden channels per slice
+constexpr int HS = TCH + 8;         // LDS row stride (bf16) of the 64-wide images: 144 B (conflict-free 16-byte row reads)
+
+template <int C> struct Cfg {
+  static constexpr int XS = C + 8;                                  // row stride of the C-wide images
+  static constexpr int CPR = C / 8;                                 // 16-byte chunks per C-wide row
+  static constexpr int NCH = 4 * C / TCH;                           // hidden slices
+  static constexpr int WS_EL = TCH * XS > C * HS ? TCH * XS : C * HS;   // W1 slice [64][C] or W2 slice [C][64]
+  static constexpr int NT = 2 * (C / 32);                           // 32 x 32 output tiles of a [64 x C] product
+  static constexpr int NTW = (NT + 3) / 4;                          // ... per wave
+  static constexpr int NX = NPIX * CPR, NXL = (NX + 255) / 256;     // chunks of the halo tile, per thread
+  static constexpr int FWD_SMEM = (NPIX * XS + WS_EL + NPIX * HS + 64 * HS) * 2 + (10 * TCH + TCH) * 4;
+  static constexpr int BWD_SMEM = (NPIX * XS + WS_EL + NPIX * HS + 64 * HS) * 2 + (9 * TCH + 4 * 10 * TCH + NCH * 10 * TCH) * 4;
+};
+
+__device__ __forceinline__ int virtual_block(int id, int n) { return (n & 7) ? id : (id & 7) * (n >> 3) + (id >> 3); }
+
+// as-it-lies [k rows][columns] image -> 32x32x16 operand of the rows-are-k kind: lane l gets X[row0 + 8h + j][l & 31], j = 0..7
+template <int LD>
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int row0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, h = g >> 1;
+  const __bf16* a = tile + (row0 + 8 * h + q) * LD + 16 * (g & 1) + 4 * p;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * LD));
+  bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return f;
+}
+template <int LD>
+__device__ __forceinline__ bf16x8 row_frag(const __bf16* tile, int row, int ks, int h) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * LD + 16 * ks + 8 * h);
+}
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { return make_uint2(pack_bf2(a, b), pack_bf2(c, d)); }
+__device__ __forceinline__ f32x2 up2(uint32_t u) { f32x2 v = {bf_lo(u), bf_hi(u)}; return v; }
+
+// eight channels of one pixel as bf16 (one 16-byte chunk of the LDS image) from a bf16 or an fp32 tensor
+template <typename T> struct Load8;
+template <> struct Load8<__bf16> {
+  static __device__ __forceinline__ u32x4 ld(const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); }
+};
+template <> struct Load8<float> {
+  static __device__ __forceinline__ u32x4 ld(const float* p) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    u32x4 v = {pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w)};
+    return v;
+  }
+};
+
+// halo pixel index 0..99 of tile (ty, tx) -> image coordinates
+struct Pix {
+  int ly, lx, gy, gx;
+  bool inb, centre;
+  __device__ __forceinline__ Pix(int pix, int ty, int tx, int hw) {
+    ly = pix / HP;
+    lx = pix - ly * HP;
+    gy = ty * TP + ly - 1;
+    gx = tx * TP + lx - 1;
+    inb = (unsigned)gy < (unsigned)hw && (unsigned)gx < (unsigned)hw;
+    centre = (unsigned)(ly - 1) < (unsigned)TP && (unsigned)(lx - 1) < (unsigned)TP;
+  }
+};
+
+// the [10 x 10] halo tile of a [tokens, C] tensor: loads (clamped addresses) and LDS stores (zero outside the image) apart,
+// so that the loads are in flight while something else is done
+template <int C, typename T>
+__device__ __forceinline__ void halo_load(u32x4 (&xr)[Cfg<C>::NXL], const T* __restrict__ src, int b, int ty, int tx, int hw, int tid) {
+  typedef Cfg<C> K;
+#pragma unroll
+  for (int k = 0; k < K::NXL; ++k) {
+    int idx = tid + 256 * k;
+    idx = idx < K::NX ? idx : K::NX - 1;
+    const int pix = idx / K::CPR, part = idx - pix * K::CPR;
+    const Pix p(pix, ty, tx, hw);
+    const int cy = min(max(p.gy, 0), hw - 1), cx = min(max(p.gx, 0), hw - 1);
+    xr[k] = Load8<T>::ld(src + (((int64_t)b * hw + cy) * hw + cx) * C + part * 8);
+  }
+}
+template <int C>
+__device__ __forceinline__ void halo_store(__bf16* Xs, const u32x4 (&xr)[Cfg<C>::NXL], int ty, int tx, int hw, int tid) {
+  typedef Cfg<C> K;
+#pragma unroll
+  for (int k = 0; k < K::NXL; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < K::NX) {
+      const int pix = idx / K::CPR, part = idx - pix * K::CPR;
+      const Pix p(pix, ty, tx, hw);
+      u32x4 v = xr[k];
+      if (!p.inb) v = (u32x4){0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(Xs + pix * K::XS + part * 8) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------ forward
+template <int C, bool SAVE>
+__global__ __launch_bounds__(256) void leff_fwd_kernel(const __bf16* __restrict__ xn2, const float* __restrict__ x1,
+                                                       const __bf16* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ wd, const float* __restrict__ bd,
+                                                       const __bf16* __restrict__ w2, const float* __restrict__ b2,
+                                                       const float* __restrict__ s2, float* __restrict__ x2,
+                                                       __bf16* __restrict__ h1, __bf16* __restrict__ h2, int B, int hw) {
+  typedef Cfg<C> K;
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // one array (> 64 KB at C = 128: dynamic allocation)
+  __bf16* const Xs = reinterpret_cast<__bf16*>(smem);                 // LayerNorm output, tile + halo (operand of fc1)
+  __bf16* const Ws = Xs + NPIX * K::XS;                               // W1 slice, then W2 slice
+  __bf16* const A1s = Ws + K::WS_EL;                                  // h1 slice, then gelu(h1) (zero outside the image)
+  __bf16* const A2s = A1s + NPIX * HS;                                // gelu(h2): A operand of fc2
+  float* const wl = reinterpret_cast<float*>(A2s + 64 * HS);          // depthwise weights [tap][channel], row 9 = bias
+  float* const b1s = wl + 10 * TCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int nt = hw / TP;
+  const int t = virtual_block(blockIdx.x, gridDim.x);                 // neighbouring tiles (shared halo rows) on one XCD
+  const int b = t / (nt * nt), tr_ = t - b * nt * nt, ty = tr_ / nt, tx = tr_ - ty * nt;
+  const int Ch = 4 * C;
+
+  u32x4 xr[K::NXL];
+  halo_load<C, __bf16>(xr, xn2, b, ty, tx, hw, tid);
+  halo_store<C>(Xs, xr, ty, tx, hw, tid);
+
+  f32x16 acc2[K::NTW];
+#pragma unroll
+  for (int i = 0; i < K::NTW; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
+  const int c2 = tid & 31, py = tid >> 5;                             // depthwise stage: two channels of one tile row
+  const int64_t row0 = (((int64_t)b * hw + ty * TP + py) * hw + tx * TP) * Ch + 2 * c2;
+
+  for (int kc = 0; kc < K::NCH; ++kc) {
+    const int hb = kc * TCH;
+    {                                                                 // W1 slice [64][C], depthwise weights, fc1 bias
+      constexpr int NL = TCH * K::CPR / 256;
+      u32x4 wreg[NL];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int idx = tid + 256 * k, row = idx / K::CPR, part = idx - row * K::CPR;
+        wreg[k] = *reinterpret_cast<const u32x4*>(w1 + (int64_t)(hb + row) * C + part * 8);
+      }
+      float wv[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        int i = tid + 256 * k;
+        i = i < 10 * TCH ? i : 10 * TCH - 1;
+        const int kk = i >> 6, c = i & 63;
+        wv[k] = kk < 9 ? wd[(hb + c) * 9 + kk] : bd[hb + c];
+      }
+      const float bv = b1[hb + (tid & 63)];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int idx = tid + 256 * k, row = idx / K::CPR, part = idx - row * K::CPR;
+        *reinterpret_cast<u32x4*>(Ws + row * K::XS + part * 8) = wreg[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (tid + 256 * k < 10 * TCH) wl[tid + 256 * k] = wv[k];
+      if (tid < TCH) b1s[tid] = bv;
+    }
+    __syncthreads();
+    // W2 slice [C][64] into registers: lands while fc1 runs
+    u32x4 w2r[C / 32];
+#pragma unroll
+    for (int k = 0; k < C / 32; ++k) {
+      const int idx = tid + 256 * k, n = idx >> 3, part = idx & 7;
+      w2r[k] = *reinterpret_cast<const u32x4*>(w2 + (int64_t)n * Ch + hb + part * 8);
+    }
+    {                                                                 // fc1: h1[hidden][pixel] = W1 slice . xn2^T
+      const int pix = 32 * wave + r;
+      const int prow = pix < NPIX ? pix : NPIX - 1;
+      f32x16 a[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[ct][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C / 16; ++ks) {
+        const bf16x8 bfrag = row_frag<K::XS>(Xs, prow, ks, h);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          a[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<K::XS>(Ws, 32 * ct + r, ks, h), bfrag, a[ct], 0, 0, 0);
+      }
+      if (pix < NPIX) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int hid = 32 * ct + 8 * g + 4 * h;
+            const float4 bb = *reinterpret_cast<const float4*>(b1s + hid);
+            *reinterpret_cast<uint2*>(A1s + pix * HS + hid) =
+                pack4(a[ct][4 * g] + bb.x, a[ct][4 * g + 1] + bb.y, a[ct][4 * g + 2] + bb.z, a[ct][4 * g + 3] + bb.w);
+          }
+      }
+    }
+    __syncthreads();
+    {                                                                 // h1 out (centre pixels), GELU in place; W2 slice -> LDS
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k;
+        if (idx < NPIX * 8) {
+          const int pix = idx >> 3, part = idx & 7;
+          const Pix p(pix, ty, tx, hw);
+          __bf16* cell = A1s + pix * HS + part * 8;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(cell);
+          if (SAVE && p.centre)
+            stream_store(h1 + (((int64_t)b * hw + p.gy) * hw + p.gx) * Ch + hb + part * 8, make_uint4(v.x, v.y, v.z, v.w));
+          u32x4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            f32x2 av, gv;
+            gelu_pair<__bf16>(up2(v[i]), av, gv);
+            o[i] = p.inb ? pack_bf2(av.x, av.y) : 0u;                 // the convolution pads gelu(h1) with zeros
+          }
+          *reinterpret_cast<u32x4*>(cell) = o;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < C / 32; ++k) {
+        const int idx = tid + 256 * k, n = idx >> 3, part = idx & 7;
+        *reinterpret_cast<u32x4*>(Ws + n * HS + part * 8) = w2r[k];
+      }
+    }
+    __syncthreads();
+    {                                                                 // depthwise 3 x 3, second GELU
+      f32x2 wr[9], br;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) wr[k] = *reinterpret_cast<const f32x2*>(wl + k * TCH + 2 * c2);
+      br = *reinterpret_cast<const f32x2*>(wl + 9 * TCH + 2 * c2);
+      auto at = [&](int dy, int x) { return up2(*reinterpret_cast<const uint32_t*>(A1s + ((py + dy) * HP + x) * HS + 2 * c2)); };
+      f32x2 col[3][3];                                                // col[x % 3][dy]
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) col[x][dy] = at(dy, x);
+#pragma unroll
+      for (int px = 0; px < TP; ++px) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) col[(px + 2) % 3][dy] = at(dy, px + 2);
+        f32x2 o = br;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) o += wr[dy * 3 + dx] * col[(px + dx) % 3][dy];
+        if (SAVE) stream_store(h2 + row0 + (int64_t)px * Ch + hb, pack_bf2(o.x, o.y));
+        f32x2 av, gv;
+        gelu_pair<__bf16>(o, av, gv);
+        *reinterpret_cast<uint32_t*>(A2s + (py * TP + px) * HS + 2 * c2) = pack_bf2(av.x, av.y);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < K::NTW; ++i) {                                // fc2: x2[token][channel] += gelu(h2) . W2 slice^T
+      const int tile = wave + 4 * i;
+      if (tile < K::NT) {
+        const int rt = tile & 1, ct = tile >> 1;
+#pragma unroll
+        for (int ks = 0; ks < TCH / 16; ++ks)
+          acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HS>(A2s, 32 * rt + r, ks, h),
+                                                            row_frag<HS>(Ws, 32 * ct + r, ks, h), acc2[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // (acc + b2) * DropPath + x1: a lane owns one channel, the 16 accumulator registers are 16 tokens
+  const float sc = s2 ? s2[b] : 1.0f;
+#pragma unroll
+  for (int i = 0; i < K::NTW; ++i) {
+    const int tile = wave + 4 * i;
+    if (tile < K::NT) {
+      const int rt = tile & 1, ct = tile >> 1, ch = 32 * ct + r;
+      const float bias = b2[ch];
+      float res[16];
+      int64_t off[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int tok = 32 * rt + mma32_row(e, h);
+        off[e] = (((int64_t)b * hw + ty * TP + (tok >> 3)) * hw + tx * TP + (tok & 7)) * C + ch;
+        res[e] = x1[off[e]];
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) __builtin_nontemporal_store((acc2[i][e] + bias) * sc + res[e], x2 + off[e]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------- backward
+// One workgroup walks the strip of tiles (b, ty, *); dw / db of the depthwise convolution are summed in LDS over the strip.
+template <int C, typename DT>
+__global__ __launch_bounds__(256) void leff_bwd_kernel(const DT* __restrict__ dy, const float* __restrict__ s2,
+                                                       const __bf16* __restrict__ h1, const __bf16* __restrict__ h2,
+                                                       const __bf16* __restrict__ w1, const float* __restrict__ wd,
+                                                       const __bf16* __restrict__ w2, __bf16* __restrict__ dh1,
+                                                       __bf16* __restrict__ dxn2, float* __restrict__ dwd,
+                                                       float* __restrict__ dbd, float* __restrict__ part, int B, int hw) {
+  typedef Cfg<C> K;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* const DYs = reinterpret_cast<__bf16*>(smem);                // incoming gradient, tile + halo; then the dxn2 tile
+  __bf16* const Ws = DYs + NPIX * K::XS;                              // W2 slice [C][64] as it lies, then W1 slice [64][C]
+  __bf16* const DH2s = Ws + K::WS_EL;                                 // h2 slice, then dh2 = (dy W2) gelu'(h2)
+  __bf16* const DH1s = DH2s + NPIX * HS;                              // dh1: operand of dxn2 += dh1 W1
+  float* const wl = reinterpret_cast<float*>(DH1s + 64 * HS);
+  float* const RED = wl + 9 * TCH;                                    // per-wave sums of the slice's dw / db
+  float* const ACC = RED + 4 * 10 * TCH;                              // [slice][tap | bias][channel] over the strip
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int nt = hw / TP;
+  const int strip = virtual_block(blockIdx.x, gridDim.x);
+  const int b = strip / nt, ty = strip - b * nt;
+  const int Ch = 4 * C;
+  const int c2 = tid & 31, py = tid >> 5;
+  const float sc = s2 ? s2[b] : 1.0f;
+  for (int i = tid; i < K::NCH * 10 * TCH; i += 256) ACC[i] = 0.f;
+
+  for (int tx = 0; tx < nt; ++tx) {
+    {
+      u32x4 xr[K::NXL];
+      halo_load<C, DT>(xr, dy, b, ty, tx, hw, tid);
+      halo_store<C>(DYs, xr, ty, tx, hw, tid);
+    }
+    f32x16 acc2[K::NTW];
+#pragma unroll
+    for (int i = 0; i < K::NTW; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
+    const int64_t row0 = (((int64_t)b * hw + ty * TP + py) * hw + tx * TP) * Ch + 2 * c2;
+
+    for (int kc = 0; kc < K::NCH; ++kc) {
+      const int hb = kc * TCH;
+      uint32_t hv[TP];                                                // h1 of this thread's 8 pixels x 2 channels
+      {                                                               // W2 slice as it lies, h2 halo slice, depthwise weights
+        u32x4 wreg[C / 32], hreg[4];
+#pragma unroll
+        for (int k = 0; k < C / 32; ++k) {
+          const int idx = tid + 256 * k, n = idx >> 3, part_ = idx & 7;
+          wreg[k] = *reinterpret_cast<const u32x4*>(w2 + (int64_t)n * Ch + hb + part_ * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          int idx = tid + 256 * k;
+          idx = idx < NPIX * 8 ? idx : NPIX * 8 - 1;
+          const int pix = idx >> 3, part_ = idx & 7;
+          const Pix p(pix, ty, tx, hw);
+          const int cy = min(max(p.gy, 0), hw - 1), cx = min(max(p.gx, 0), hw - 1);
+          hreg[k] = *reinterpret_cast<const u32x4*>(h2 + (((int64_t)b * hw + cy) * hw + cx) * Ch + hb + part_ * 8);
+        }
+        float wv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          int i = tid + 256 * k;
+          i = i < 9 * TCH ? i : 9 * TCH - 1;
+          wv[k] = wd[(hb + (i & 63)) * 9 + (i >> 6)];
+        }
+#pragma unroll
+        for (int px = 0; px < TP; ++px) hv[px] = *reinterpret_cast<const uint32_t*>(h1 + row0 + (int64_t)px * Ch + hb);
+#pragma unroll
+        for (int k = 0; k < C / 32; ++k) {
+          const int idx = tid + 256 * k, n = idx >> 3, part_ = idx & 7;
+          *reinterpret_cast<u32x4*>(Ws + n * HS + part_ * 8) = wreg[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int idx = tid + 256 * k;
+          if (idx < NPIX * 8) *reinterpret_cast<u32x4*>(DH2s + (idx >> 3) * HS + (idx & 7) * 8) = hreg[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (tid + 256 * k < 9 * TCH) wl[tid + 256 * k] = wv[k];
+      }
+      __syncthreads();
+      // W1 slice [64][C] into registers: lands while the first product runs
+      constexpr int NL1 = TCH * K::CPR / 256;
+      u32x4 w1r[NL1];
+#pragma unroll
+      for (int k = 0; k < NL1; ++k) {
+        const int idx = tid + 256 * k, row = idx / K::CPR, part_ = idx - row * K::CPR;
+        w1r[k] = *reinterpret_cast<const u32x4*>(w1 + (int64_t)(hb + row) * C + part_ * 8);
+      }
+      {                                                               // dh2[hidden][pixel] = (W2 slice)^T dy^T, times gelu'(h2)
+        const int pix = 32 * wave + r;
+        const int prow = pix < NPIX ? pix : NPIX - 1;
+        f32x16 a[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) a[ct][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < C / 16; ++ks) {
+          const bf16x8 bfrag = row_frag<K::XS>(DYs, prow, ks, h);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+            a[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HS>(Ws + 32 * ct, 16 * ks, lane), bfrag, a[ct], 0, 0, 0);
+        }
+        if (pix < NPIX) {
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              uint2* cell = reinterpret_cast<uint2*>(DH2s + pix * HS + 32 * ct + 8 * g + 4 * h);
+              const uint2 hraw = *cell;
+              f32x2 a01, g01, a23, g23;
+              gelu_pair<__bf16>(up2(hraw.x), a01, g01);
+              gelu_pair<__bf16>(up2(hraw.y), a23, g23);
+              *cell = pack4(a[ct][4 * g] * sc * g01.x, a[ct][4 * g + 1] * sc * g01.y, a[ct][4 * g + 2] * sc * g23.x,
+                            a[ct][4 * g + 3] * sc * g23.y);
+            }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NL1; ++k) {                                 // W1 slice as it lies (the first product is done with Ws)
+        const int idx = tid + 256 * k, row = idx / K::CPR, part_ = idx - row * K::CPR;
+        *reinterpret_cast<u32x4*>(Ws + row * K::XS + part_ * 8) = w1r[k];
+      }
+      {                                                               // transposed depthwise conv, gelu'(h1); dw / db sums
+        f32x2 wr[9], aw[9], ab = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          wr[k] = *reinterpret_cast<const f32x2*>(wl + k * TCH + 2 * c2);
+          aw[k] = (f32x2){0.f, 0.f};
+        }
+        auto at = [&](int rr, int x) { return up2(*reinterpret_cast<const uint32_t*>(DH2s + ((py + rr) * HP + x) * HS + 2 * c2)); };
+        f32x2 col[3][3];                                              // col[x % 3][row]
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) col[x][rr] = at(rr, x);
+#pragma unroll
+        for (int px = 0; px < TP; ++px) {
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) col[(px + 2) % 3][rr] = at(rr, px + 2);
+          f32x2 a1, gp;
+          gelu_pair<__bf16>(up2(hv[px]), a1, gp);
+          f32x2 o = {0.f, 0.f};
+#pragma unroll
+          for (int dy_ = 0; dy_ < 3; ++dy_)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const f32x2 g = col[(px + 2 - dx) % 3][2 - dy_];         // dh2 at (py + 1 - (dy - 1), px + 1 - (dx - 1))
+              o += wr[dy_ * 3 + dx] * g;
+              aw[dy_ * 3 + dx] += a1 * g;
+            }
+          ab += col[(px + 1) % 3][1];
+          const f32x2 d = o * gp;
+          const uint32_t packed = pack_bf2(d.x, d.y);
+          stream_store(dh1 + row0 + (int64_t)px * Ch + hb, packed);
+          *reinterpret_cast<uint32_t*>(DH1s + (py * TP + px) * HS + 2 * c2) = packed;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          aw[k].x += __shfl_xor(aw[k].x, 32);
+          aw[k].y += __shfl_xor(aw[k].y, 32);
+        }
+        ab.x += __shfl_xor(ab.x, 32);
+        ab.y += __shfl_xor(ab.y, 32);
+        if (lane < 32) {
+          float* dst = RED + wave * 10 * TCH + 2 * c2;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) *reinterpret_cast<float2*>(dst + k * TCH) = make_float2(aw[k].x, aw[k].y);
+          *reinterpret_cast<float2*>(dst + 9 * TCH) = make_float2(ab.x, ab.y);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < K::NTW; ++i) {                              // dxn2[channel][token] += (W1 slice)^T dh1^T
+        const int tile = wave + 4 * i;
+        if (tile < K::NT) {
+          const int rt = tile & 1, ct = tile >> 1;
+#pragma unroll
+          for (int ks = 0; ks < TCH / 16; ++ks)
+            acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<K::XS>(Ws + 32 * ct, 16 * ks, lane),
+                                                              row_frag<HS>(DH1s, 32 * rt + r, ks, h), acc2[i], 0, 0, 0);
+        }
+      }
+      for (int i = tid; i < 10 * TCH; i += 256)
+        ACC[kc * 10 * TCH + i] += (RED[i] + RED[10 * TCH + i]) + (RED[2 * 10 * TCH + i] + RED[3 * 10 * TCH + i]);
+      __syncthreads();
+    }
+    // dxn2 tile: [channel on the registers][token on the lane] -> LDS [token][C] -> 16-byte rows
+#pragma unroll
+    for (int i = 0; i < K::NTW; ++i) {
+      const int tile = wave + 4 * i;
+      if (tile < K::NT) {
+        const int rt = tile & 1, ct = tile >> 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<uint2*>(DYs + (32 * rt + r) * K::XS + 32 * ct + 8 * g + 4 * h) =
+              pack4(acc2[i][4 * g], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < C / 32; ++k) {
+      const int idx = tid + 256 * k, tok = idx / K::CPR, part_ = idx - tok * K::CPR;
+      const int64_t grow = ((int64_t)b * hw + ty * TP + (tok >> 3)) * hw + tx * TP + (tok & 7);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(DYs + tok * K::XS + part_ * 8);
+      stream_store(dxn2 + grow * C + part_ * 8, make_uint4(v.x, v.y, v.z, v.w));
+    }
+    __syncthreads();
+  }
+  // the strip's dw [Ch][9] / db [Ch] as part[strip][Ch][10] (summed by the deferred reduction), or atomics without scratch
+  for (int i = tid; i < Ch * 10; i += 256) {
+    const int ch = i / 10, k = i - ch * 10;
+    const float v = ACC[(ch >> 6) * 10 * TCH + k * TCH + (ch & 63)];
+    if (part) part[(int64_t)strip * Ch * 10 + i] = v;
+    else if (k < 9) atomicAdd(dwd + ch * 9 + k, v);
+    else atomicAdd(dbd + ch, v);
+  }
+}
+
+bool ok(int B, int hw, int C) { return B > 0 && hw >= 8 && (hw & 7) == 0 && (C == 32 || C == 64 || C == 128); }
+
+template <int C>
+int launch_fwd(const void* xn2, const float* x1, const void* w1, const float* b1, const float* wd, const float* bd, const void* w2,
+               const float* b2, const float* s2, float* x2, void* h1, void* h2, int B, int hw, hipStream_t st) {
+  const int tiles = B * (hw / TP) * (hw / TP);
+  constexpr int SM = Cfg<C>::FWD_SMEM;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leff_fwd_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leff_fwd_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
+    attr = true;
+  }
+  if (h1 && h2)
+    hipLaunchKernelGGL((leff_fwd_kernel<C, true>), dim3(tiles), dim3(256), SM, st, static_cast<const __bf16*>(xn2), x1,
+                       static_cast<const __bf16*>(w1), b1, wd, bd, static_cast<const __bf16*>(w2), b2, s2, x2,
+                       static_cast<__bf16*>(h1), static_cast<__bf16*>(h2), B, hw);
+  else
+    hipLaunchKernelGGL((leff_fwd_kernel<C, false>), dim3(tiles), dim3(256), SM, st, static_cast<const __bf16*>(xn2), x1,
+                       static_cast<const __bf16*>(w1), b1, wd, bd, static_cast<const __bf16*>(w2), b2, s2, x2,
+                       static_cast<__bf16*>(nullptr), static_cast<__bf16*>(nullptr), B, hw);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+template <int C>
+int launch_bwd(const void* dy, int dy_bf16, const float* s2, const void* h1, const void* h2, const void* w1, const float* wd,
+               const void* w2, void* dh1, void* dxn2, float* dwd, float* dbd, float* scratch, int B, int hw, hipStream_t st) {
+  const int strips = B * (hw / TP);
+  constexpr int SM = Cfg<C>::BWD_SMEM;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leff_bwd_kernel<C, __bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leff_bwd_kernel<C, float>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
+    attr = true;
+  }
+  if (dy_bf16)
+    hipLaunchKernelGGL((leff_bwd_kernel<C, __bf16>), dim3(strips), dim3(256), SM, st, static_cast<const __bf16*>(dy), s2,
+                       static_cast<const __bf16*>(h1), static_cast<const __bf16*>(h2), static_cast<const __bf16*>(w1), wd,
+                       static_cast<const __bf16*>(w2), static_cast<__bf16*>(dh1), static_cast<__bf16*>(dxn2), dwd, dbd, scratch, B, hw);
+  else
+    hipLaunchKernelGGL((leff_bwd_kernel<C, float>), dim3(strips), dim3(256), SM, st, static_cast<const float*>(dy), s2,
+                       static_cast<const __bf16*>(h1), static_cast<const __bf16*>(h2), static_cast<const __bf16*>(w1), wd,
+                       static_cast<const __bf16*>(w2), static_cast<__bf16*>(dh1), static_cast<__bf16*>(dxn2), dwd, dbd, scratch, B, hw);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t wm_leff_fusable(int32_t hw, int32_t C) { return ok(1, hw, C) ? 1 : 0; }
+
+extern "C" int wm_leff_fwd(const void* xn2, const float* x1, const void* w1, const float* b1, const float* wd, const float* bd,
+                           const void* w2, const float* b2, const float* rowscale, float* x2, void* h1, void* h2, int32_t B,
+                           int32_t hw, int32_t C, void* stream) {
+  if (!xn2 || !x1 || !w1 || !b1 || !wd || !bd || !w2 || !b2 || !x2 || (!h1) != (!h2) || !ok(B, hw, C)) return WM_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (C == 32) return launch_fwd<32>(xn2, x1, w1, b1, wd, bd, w2, b2, rowscale, x2, h1, h2, B, hw, st);
+  if (C == 64) return launch_fwd<64>(xn2, x1, w1, b1, wd, bd, w2, b2, rowscale, x2, h1, h2, B, hw, st);
+  return launch_fwd<128>(xn2, x1, w1, b1, wd, bd, w2, b2, rowscale, x2, h1, h2, B, hw, st);
+}
+
+extern "C" int64_t wm_leff_bwd_scratch_floats(int32_t B, int32_t hw, int32_t C) { return (int64_t)B * (hw / TP) * 4 * C * 10; }
+
+extern "C" int wm_leff_bwd(const void* dy, int32_t dy_bf16, const float* rowscale, const void* h1, const void* h2, const void* w1,
+                           const float* wd, const void* w2, void* dh1, void* dxn2, float* dwd, float* dbd, float* scratch,
+                           WmReduceJob* defer, int32_t B, int32_t hw, int32_t C, void* stream) {
+  if (!dy || !h1 || !h2 || !w1 || !wd || !w2 || !dh1 || !dxn2 || !dwd || !dbd || !ok(B, hw, C)) return WM_EINVAL;
+  if (defer && !scratch) return WM_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc;
+  if (C == 32) rc = launch_bwd<32>(dy, dy_bf16, rowscale, h1, h2, w1, wd, w2, dh1, dxn2, dwd, dbd, scratch, B, hw, st);
+  else if (C == 64) rc = launch_bwd<64>(dy, dy_bf16, rowscale, h1, h2, w1, wd, w2, dh1, dxn2, dwd, dbd, scratch, B, hw, st);
+  else rc = launch_bwd<128>(dy, dy_bf16, rowscale, h1, h2, w1, wd, w2, dh1, dxn2, dwd, dbd, scratch, B, hw, st);
+  if (rc != WM_OK || !scratch) return rc;
+  const int Ch = 4 * C, P = B * (hw / TP);
+  WmReduceJob jw{}, jb{};
+  jw.src = scratch; jw.pstride = (int64_t)Ch * 10; jw.src_ld = 10; jw.count = P; jw.rows = Ch; jw.cols = 9;
+  jw.dst = dwd; jw.dst_rs = 9; jw.dst_cs = 1;
+  jb = jw;
+  jb.src = scratch + 9; jb.cols = 1; jb.dst = dbd; jb.dst_rs = 1;
+  if (defer) {
+    defer[0] = jw;
+    defer[1] = jb;
+    return WM_OK;
+  }
+  WmReduceJob both[2] = {jw, jb};
+  return wm_reduce_jobs(both, 2, stream);
+}

@@ -484,6 +484,15 @@ class UformerAudio(nn.Module):
         else:
             ops.linear_fwd(o, W(pre + "attn.proj.weight"), P[pre + "attn.proj.bias"], x1, mode, res=x, rowscale=s1, rows_per_scale=N)
             ops.layernorm_fwd(x1, P[pre + "norm2.weight"], P[pre + "norm2.bias"], None, xn2, mean2, rstd2, hw, 0)
+        if half and ops.leff_fusable(hw, C):
+            # C <= 128: fc1 -> GELU -> depthwise 3 x 3 -> GELU -> fc2 (+ DropPath, + residual) as ONE launch that keeps an 8 x 8-pixel
+            # tile on chip (csrc/leff_fused.hip); h1 / h2 are the two pre-activations, all the backward needs
+            h1, h2 = H(dev, M, 4 * C), H(dev, M, 4 * C)
+            x2 = _E(dev, M, C)
+            ops.leff_fwd(xn2, x1, W(pre + "mlp.linear1.0.weight"), P[pre + "mlp.linear1.0.bias"], P[pre + "mlp.dwconv.0.weight"],
+                         P[pre + "mlp.dwconv.0.bias"], W(pre + "mlp.linear2.0.weight"), P[pre + "mlp.linear2.0.bias"], x2, B, hw, C,
+                         rowscale=s2, h1=h1, h2=h2)
+            return x2, (pre, x, B, C, hw, shift, s1, s2, mod, xn1, mean1, rstd1, qkv, o, x1, xn2, mean2, rstd2, h1, h2, None, lse), None
         h1 = H(dev, M, 4 * C)
         ops.linear_fwd(xn2, W(pre + "mlp.linear1.0.weight"), P[pre + "mlp.linear1.0.bias"], h1, mode)
         a2, h2 = H(dev, M, 4 * C), H(dev, M, 4 * C)       # h2 holds gelu'(dwconv output): all backward needs of it
@@ -511,20 +520,28 @@ class UformerAudio(nn.Module):
         (sg0, sg1, sg2, sg3, sl0, sl1, sdw, sat), jobs = self._block_scratch(dev, B, hw, C)
         # LeFF
         H, W = self._H, self._W
-        dh2 = H(dev, M, 4 * C)
         half = self.compute_mode == "bf16"
         dyg = dyh if dyh is not None else dy                       # GEMM operand: the bf16 copy when there is one
         s2g = None if dyh is not None else s2                      # ... which already holds dy * s2
         WT = self._WT
-        ops.linear_bwd_input(dyg, W(pre + "mlp.linear2.0.weight"), dh2, mode, rowscale=s2g, rows_per_scale=N, gaux=h2, gaux_raw=True,
-                             wT=WT(pre + "mlp.linear2.0.weight"))
-        ops.linear_bwd_weight(dyg, a2, G[pre + "mlp.linear2.0.weight"], G[pre + "mlp.linear2.0.bias"], mode,
-                              kscale=s2g, k_per_scale=N, scratch=sg0, defer=jobs.take(1))
-        dh1 = H(dev, M, 4 * C)
-        ops.dwconv_bwd(h1, dh2, P[pre + "mlp.dwconv.0.weight"], dh1, G[pre + "mlp.dwconv.0.weight"],
-                       G[pre + "mlp.dwconv.0.bias"], B, hw, 4 * C, scratch=sdw, defer=jobs.take(2))
-        dxn2 = H(dev, M, C)
-        ops.linear_bwd_input(dh1, W(pre + "mlp.linear1.0.weight"), dxn2, mode, wT=WT(pre + "mlp.linear1.0.weight"))
+        dh1, dxn2 = H(dev, M, 4 * C), H(dev, M, C)
+        if a2 is None:
+            # fused LeFF (forward took it): linear2's input gradient, the transposed depthwise convolution and linear1's input
+            # gradient in one launch; h2 is the PRE-activation here, so linear2's weight gradient applies GELU while staging it
+            ops.leff_bwd(dyg, h1, h2, W(pre + "mlp.linear1.0.weight"), P[pre + "mlp.dwconv.0.weight"], W(pre + "mlp.linear2.0.weight"),
+                         dh1, dxn2, G[pre + "mlp.dwconv.0.weight"], G[pre + "mlp.dwconv.0.bias"], B, hw, C, rowscale=s2g,
+                         scratch=sdw, defer=jobs.take(2))
+            ops.linear_bwd_weight(dyg, h2, G[pre + "mlp.linear2.0.weight"], G[pre + "mlp.linear2.0.bias"], mode, x_op=1,
+                                  kscale=s2g, k_per_scale=N, scratch=sg0, defer=jobs.take(1))
+        else:
+            dh2 = H(dev, M, 4 * C)
+            ops.linear_bwd_input(dyg, W(pre + "mlp.linear2.0.weight"), dh2, mode, rowscale=s2g, rows_per_scale=N, gaux=h2, gaux_raw=True,
+                                 wT=WT(pre + "mlp.linear2.0.weight"))
+            ops.linear_bwd_weight(dyg, a2, G[pre + "mlp.linear2.0.weight"], G[pre + "mlp.linear2.0.bias"], mode,
+                                  kscale=s2g, k_per_scale=N, scratch=sg0, defer=jobs.take(1))
+            ops.dwconv_bwd(h1, dh2, P[pre + "mlp.dwconv.0.weight"], dh1, G[pre + "mlp.dwconv.0.weight"],
+                           G[pre + "mlp.dwconv.0.bias"], B, hw, 4 * C, scratch=sdw, defer=jobs.take(2))
+            ops.linear_bwd_input(dh1, W(pre + "mlp.linear1.0.weight"), dxn2, mode, wT=WT(pre + "mlp.linear1.0.weight"))
         ops.linear_bwd_weight(dh1, xn2, G[pre + "mlp.linear1.0.weight"], G[pre + "mlp.linear1.0.bias"], mode, scratch=sg1,
                               defer=jobs.take(1))
         dx1 = _E(dev, M, C)

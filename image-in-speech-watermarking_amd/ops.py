@@ -138,6 +138,35 @@ def dwconv_bwd(h1, dh2, w, dh1, dw, db, B, hw, Ch, scratch=None, defer=None):
                             _stream()), "wm_dwconv_bwd")
 
 
+def leff_fusable(hw, Cc):
+    """Do the fused LeFF kernels (csrc/leff_fused.hip) take this block?  (WM_NO_LEFF_FUSE=1: never — the A/B switch.)"""
+    import os
+    if os.environ.get("WM_NO_LEFF_FUSE", "0") == "1":
+        return False
+    return bool(lib.wm_leff_fusable(hw, Cc))
+
+
+def leff_fwd(xn2, x1, w1, b1, wd, bd, w2, b2, x2, B, hw, Cc, rowscale=None, h1=None, h2=None):
+    """x2 = (gelu(dwconv3x3(gelu(xn2 @ w1^T + b1)) + bd) @ w2^T + b2) * rowscale[sample] + x1 in one launch; h1 / h2 (bf16,
+    both or neither): the two pre-activations, kept for leff_bwd."""
+    for t in (xn2, w1, w2, h1, h2):
+        if t is not None and t.dtype != torch.bfloat16:
+            raise ValueError("leff_fwd: xn2, w1, w2, h1, h2 are bfloat16 tensors (bf16 mode only)")
+    check(lib.wm_leff_fwd(ptr(xn2), ptr(x1), ptr(w1), ptr(b1), ptr(wd), ptr(bd), ptr(w2), ptr(b2), ptr(rowscale), ptr(x2),
+                          ptr(h1), ptr(h2), B, hw, Cc, _stream()), "wm_leff_fwd")
+
+
+def leff_bwd(dy, h1, h2, w1, wd, w2, dh1, dxn2, dwd, dbd, B, hw, Cc, rowscale=None, scratch=None, defer=None):
+    """dh1 = gelu'(h1) * dwconv^T(((dy * rowscale) @ w2) * gelu'(h2)), dxn2 = dh1 @ w1; dwd / dbd accumulated."""
+    for t in (h1, h2, w1, w2, dh1, dxn2):
+        if t.dtype != torch.bfloat16:
+            raise ValueError("leff_bwd: h1, h2, w1, w2, dh1, dxn2 are bfloat16 tensors (bf16 mode only)")
+    if scratch is not None and scratch.numel() < lib.wm_leff_bwd_scratch_floats(B, hw, Cc):
+        raise ValueError("leff_bwd: scratch buffer too small")
+    check(lib.wm_leff_bwd(ptr(dy), _bf(dy), ptr(rowscale), ptr(h1), ptr(h2), ptr(w1), ptr(wd), ptr(w2), ptr(dh1), ptr(dxn2),
+                          ptr(dwd), ptr(dbd), ptr(scratch), defer, B, hw, Cc, _stream()), "wm_leff_bwd")
+
+
 def im2col(x, cols, B, hw, Cc):
     check(lib.wm_im2col_4x4s2(ptr(x), ptr(cols), _bf(cols), B, hw, Cc, _stream()), "wm_im2col_4x4s2")
 

@@ -40,6 +40,12 @@ COST = {
     "winattn_bwd": lambda qkv, t, do, dq, dt, B, hw, C, sh, mode, out=None, lse=None, scratch=None, defer=None: (_attn_cost(B, hw, C, 6), qkv.element_size() * B * hw * hw * 8.0 * C),   # q|k|v, dO, O read; dq|dk|dv written
     "dwconv_fwd": lambda h1, w, b, h2, B, hw, Ch, a2=None, g2=None: (18.0 * B * hw * hw * Ch, (1.0 + sum(t is not None for t in (h2, a2, g2))) * h1.element_size() * B * hw * hw * Ch),
     "dwconv_bwd": lambda h1, d, w, dh, dw, db, B, hw, Ch, scratch=None, defer=None: (54.0 * B * hw * hw * Ch, 3.0 * h1.element_size() * B * hw * hw * Ch),
+    # fused LeFF (C <= 128): two [tokens x C x 4C] products + the depthwise taps; xn2 / dy read, x1 read, x2 / dxn2 written, the two
+    # saved pre-activations written (forward) or read (backward) and dh1 written (halo re-reads are L2 traffic, not algorithmic)
+    "leff_fwd": lambda xn2, x1, w1, b1, wd, bd, w2, b2, x2, B, hw, C, rowscale=None, h1=None, h2=None:
+        (16.0 * B * hw * hw * C * C + 72.0 * B * hw * hw * C, B * hw * hw * C * (10.0 + (16.0 if h1 is not None else 0.0))),
+    "leff_bwd": lambda dy, h1, h2, w1, wd, w2, dh1, dxn2, dwd, dbd, B, hw, C, rowscale=None, scratch=None, defer=None:
+        (16.0 * B * hw * hw * C * C + 216.0 * B * hw * hw * C, B * hw * hw * C * (dy.element_size() + 26.0)),
     "layernorm_fwd": lambda x, g, b, m, y, *a: (8.0 * x.numel(), (4.0 + y.element_size()) * x.numel()),
     # dy, x and the residual gradient read, dx written (+ its bf16 copy for the next GEMM when asked for)
     "layernorm_bwd": lambda dy, x, *a, **k: (16.0 * x.numel(), (12.0 + dy.element_size() + (2.0 if k.get("dx_bf16") is not None else 0.0)) * x.numel()),

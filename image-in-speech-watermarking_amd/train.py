@@ -12,15 +12,20 @@ import torch.distributed as dist
 from . import ops
 
 
-class FusedAdamW:
+class FusedAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (lr 2e-4, betas 0.9/0.999, eps 1e-8, wd 0.02 at audio_uformer_stft.py:252-255)
     applied to the model's flat parameter arena by ONE kernel.  lr / step / grad-scale live in device memory so a
-    captured graph follows the LR schedule."""
+    captured graph follows the LR schedule.
+
+    It IS a ``torch.optim.Optimizer`` (one param group holding the model's Parameters, which are views of the arena), so the
+    reference trainer's scheduler construction works unchanged (audio_uformer_stft.py:347-356): ``CosineAnnealingLR(opt, ...)``,
+    the reference's ``GradualWarmupScheduler(opt, ...)`` (or ``train.GradualWarmupScheduler``, the same rule) and ``StepLR``
+    write ``param_groups[0]['lr']``; ``step()`` / ``TrainStep.step()`` copy it to the device scalar the kernel reads
+    (``sync_lr``), also between replays of a captured step."""
 
     def __init__(self, net, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02):
         self.net = net
-        self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        self.param_groups = [dict(self.defaults, params=list(net.parameters()))]   # LR schedulers poke 'lr' here
+        super().__init__(list(net.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         dev = net._flat.device
         n = net.optimized_numel
         self.exp_avg = torch.zeros(n, device=dev)
@@ -30,6 +35,11 @@ class FusedAdamW:
         self.grad_scale_t = torch.ones(1, device=dev)
         self._lr_host = float(lr)
 
+    def add_param_group(self, param_group):
+        if getattr(self, "param_groups", None):
+            raise ValueError("FusedAdamW updates the model's whole parameter arena with one set of hyper-parameters: one param group")
+        super().add_param_group(param_group)
+
     def sync_lr(self):
         lr = float(self.param_groups[0]["lr"])
         if lr != self._lr_host:
@@ -37,11 +47,17 @@ class FusedAdamW:
             self._lr_host = lr
 
     def zero_grad(self, set_to_none=False):
+        """Zeroes the gradient arena in place (the Parameters' ``.grad`` stay views of it, whatever ``set_to_none`` says)."""
         self.net._flat_grad.zero_()
 
-    def step(self):
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         self.sync_lr()
         self.launch()
+        return loss
 
     def launch(self):
         """Graph-capturable part of step()."""
@@ -58,6 +74,43 @@ class FusedAdamW:
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.step_t.copy_(sd["step"])
         self.param_groups[0]["lr"] = sd["lr"]
         self.sync_lr()
+
+
+class GradualWarmupScheduler(torch.optim.lr_scheduler.LRScheduler):
+    """Linear warm-up in front of another scheduler, the rule of the reference's ``warmup_scheduler/scheduler.py:5-63`` as the
+    trainer uses it (audio_uformer_stft.py:347-356: ``multiplier=1, total_epoch=warmup_epochs, after_scheduler=cosine``):
+    epoch e <= total_epoch: lr = base_lr * e / total_epoch (multiplier 1) or base_lr * ((multiplier - 1) e / total_epoch + 1);
+    afterwards the wrapped scheduler runs from base_lr * multiplier, stepped once per call.  (The ReduceLROnPlateau branch of the
+    reference class is not on the trainer's path and is left out.)"""
+
+    def __init__(self, optimizer, multiplier, total_epoch, after_scheduler=None):
+        if multiplier < 1.0:
+            raise ValueError("multiplier should be greater than or equal to 1.")
+        self.multiplier, self.total_epoch, self.after_scheduler = multiplier, total_epoch, after_scheduler
+        self.finished = False
+        super().__init__(optimizer)
+
+    def get_lr(self):
+        if self.last_epoch > self.total_epoch:
+            if self.after_scheduler is not None:
+                if not self.finished:
+                    self.after_scheduler.base_lrs = [b * self.multiplier for b in self.base_lrs]
+                    self.finished = True
+                # the hand-over epoch asks the wrapped scheduler's get_lr() directly, as the reference class does: with a chained
+                # CosineAnnealingLR that is its recursive form evaluated at ITS epoch 0 (tests/test_host_cpu.py holds the whole
+                # sequence to the reference's class under the installed torch)
+                return self.after_scheduler.get_lr()
+            return [b * self.multiplier for b in self.base_lrs]
+        if self.multiplier == 1.0:
+            return [b * (float(self.last_epoch) / self.total_epoch) for b in self.base_lrs]
+        return [b * ((self.multiplier - 1.0) * self.last_epoch / self.total_epoch + 1.0) for b in self.base_lrs]
+
+    def step(self, epoch=None):
+        if self.finished and self.after_scheduler is not None:
+            self.after_scheduler.step(None if epoch is None else epoch - self.total_epoch)
+            self._last_lr = self.after_scheduler.get_last_lr()
+            return
+        super().step(epoch)
 
 
 class GradSync:

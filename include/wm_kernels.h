@@ -124,6 +124,26 @@ int64_t wm_dwconv_bwd_scratch_floats(int32_t B, int32_t hw, int32_t Ch);
 int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, void* dh1, float* dw, float* db, float* scratch,
                   WmReduceJob* defer /* 2 entries or NULL */, int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream);
 
+/* ---- LeFF as two fused kernels (blocks with C in {32, 64, 128}, bf16 storage) — model.py:695-714 + the residual / DropPath add of
+ * :1016-1017.  Replaces, for those blocks, linear1 + wm_dwconv_fwd + linear2 (forward) and linear2's input gradient +
+ * wm_dwconv_bwd + linear1's input gradient (backward); the two weight-gradient products stay on wm_gemm (fc2's reads the saved
+ * h2 with GELU applied while staging: b_op = 1).  An 8 x 8-pixel tile stays in LDS / registers across the three operators.
+ *   forward : x2 = (gelu(dwconv3x3(gelu(xn2 W1^T + b1)) + bd) W2^T + b2) * rowscale[sample] + x1
+ *             xn2 [tokens, C] bf16 (LayerNorm output), x1 / x2 [tokens, C] fp32, w1 [4C, C] / w2 [C, 4C] bf16 copies of the
+ *             parameters, wd [4C, 9] / bd [4C] fp32; h1, h2 [tokens, 4C] bf16 (both or neither): the two pre-activations,
+ *             saved for the backward.
+ *   backward: dy [tokens, C] (bf16 copy or fp32) -> dh1 [tokens, 4C] bf16 (operand of fc1's weight gradient) and
+ *             dxn2 [tokens, C] bf16; dwd [4C, 9] / dbd [4C] accumulated (scratch: >= wm_leff_bwd_scratch_floats floats of
+ *             per-strip partial sums, reduced by wm_reduce_jobs — deferred into 2 entries when `defer` is given; NULL = atomics). */
+int32_t wm_leff_fusable(int32_t hw, int32_t C);
+int wm_leff_fwd(const void* xn2, const float* x1, const void* w1_bf16, const float* b1, const float* wd, const float* bd,
+                const void* w2_bf16, const float* b2, const float* rowscale /* [B] or NULL */, float* x2, void* h1, void* h2,
+                int32_t B, int32_t hw, int32_t C, void* stream);
+int64_t wm_leff_bwd_scratch_floats(int32_t B, int32_t hw, int32_t C);
+int wm_leff_bwd(const void* dy, int32_t dy_bf16, const float* rowscale /* [B] or NULL */, const void* h1, const void* h2,
+                const void* w1_bf16, const float* wd, const void* w2_bf16, void* dh1, void* dxn2, float* dwd, float* dbd,
+                float* scratch, WmReduceJob* defer /* 2 entries or NULL */, int32_t B, int32_t hw, int32_t C, void* stream);
+
 /* ---- data movement for Downsample (conv4x4 s2 p1, model.py:763) / Upsample (convT2x2 s2, :789) */
 int wm_im2col_4x4s2(const float* x, void* cols, int32_t cols_bf16, int32_t B, int32_t hw, int32_t C, void* stream);
 int wm_col2im_4x4s2(const void* dcols, int32_t dcols_bf16, float* dx, int32_t B, int32_t hw, int32_t C, void* stream);

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(wm):
     nm = subprocess.run(["nm", "-D", "--defined-only", wm.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (wm_[a-z0-9_]+)", nm))
     assert declared <= exported
-    assert wm.lib.wm_abi_version() == 5
+    assert wm.lib.wm_abi_version() == 6
 
 
 def test_model_surface_matches_reference(wm):
@@ -289,3 +289,57 @@ def test_bench_usable_cores_follows_the_cgroup_quota(monkeypatch):
     assert bench.usable_cores()[0] == 128                           # SMT pairs of the 256 visible CPUs
     monkeypatch.setattr(builtins, "open", fake_open(None))
     assert bench.usable_cores()[0] == 128
+
+
+def _lr_sequence(make_warmup, opt, nepoch=12, warm=3):
+    """The reference trainer's scheduler construction (uformerWM/audio_uformer_stft.py:347-356) and its per-epoch stepping."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cosine = torch.optim.lr_scheduler.CosineAnnealingLR(opt, nepoch - warm, eta_min=1e-6)
+        sched = make_warmup(opt, multiplier=1, total_epoch=warm, after_scheduler=cosine)
+        sched.step()
+        out = []
+        for _ in range(nepoch + 2):
+            out.append(opt.param_groups[0]["lr"])
+            sched.step()
+    return out
+
+
+def test_fused_adamw_is_an_optimizer_the_reference_schedulers_accept(wm):
+    """CosineAnnealingLR / GradualWarmupScheduler / StepLR raised 'is not an Optimizer' on FusedAdamW."""
+    tr = importlib.import_module("image-in-speech-watermarking_amd.train")
+    net = wm.UformerAudio(modulator=True)
+    opt = tr.FusedAdamW(net, lr=2e-4, weight_decay=0.02)
+    assert isinstance(opt, torch.optim.Optimizer)
+    assert len(opt.param_groups) == 1 and len(opt.param_groups[0]["params"]) == len(list(net.parameters()))
+    with pytest.raises(ValueError):
+        opt.add_param_group({"params": [torch.nn.Parameter(torch.zeros(1))]})
+    # the package's warm-up wrapper on FusedAdamW == the same wrapper on a stock AdamW
+    stock = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(3))], lr=2e-4)
+    mine = _lr_sequence(tr.GradualWarmupScheduler, opt)
+    assert mine == _lr_sequence(tr.GradualWarmupScheduler, stock)
+    assert mine[0] == pytest.approx(2e-4 / 3) and mine[2] == pytest.approx(2e-4) and min(mine) == pytest.approx(1e-6)
+    # StepLR, the trainer's other branch (audio_uformer_stft.py:357-360)
+    opt2 = tr.FusedAdamW(net, lr=2e-4)
+    st = torch.optim.lr_scheduler.StepLR(opt2, step_size=10, gamma=0.5)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(10):
+            st.step()
+    assert opt2.param_groups[0]["lr"] == pytest.approx(1e-4)
+    # with the reference tree at hand (build container): its own GradualWarmupScheduler class drives FusedAdamW, and the package's
+    # restatement produces the same learning rates epoch by epoch under the installed torch
+    ref_dir = "/root/reference/uformerWM"
+    if os.path.isdir(ref_dir):
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, ref_dir)
+        try:
+            from warmup_scheduler.scheduler import GradualWarmupScheduler as RefWarmup
+        finally:
+            sys.path.remove(ref_dir)
+        ref_on_stock = _lr_sequence(RefWarmup, torch.optim.AdamW([torch.nn.Parameter(torch.zeros(3))], lr=2e-4))
+        ref_on_fused = _lr_sequence(RefWarmup, tr.FusedAdamW(net, lr=2e-4))
+        assert ref_on_fused == ref_on_stock
+        assert mine == ref_on_stock
