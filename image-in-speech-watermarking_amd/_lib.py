@@ -144,7 +144,7 @@ EXPORTS = tuple(_SIGS)
 
 
 class WmKernelError(RuntimeError):
-    pass
+    code = None                                   # the C entry point's return value (22 = WM_EINVAL), when there was one
 
 
 def _load():
@@ -166,7 +166,9 @@ lib = _load()
 
 def check(rc, what):
     if rc != 0:
-        raise WmKernelError(f"{what} failed with code {rc}" + (" (unsupported shape/alignment)" if rc == 22 else ""))
+        err = WmKernelError(f"{what} failed with code {rc}" + (" (unsupported shape/alignment)" if rc == 22 else ""))
+        err.code = int(rc)
+        raise err
 
 
 def ptr(t):

@@ -68,9 +68,11 @@ __device__ __forceinline__ bf16x8 lds_read_tr(uint32_t addr, int) {          // 
   }
 
 // ------------------------------------------------------------------------------------------------------------------
-#define WM_PP_DBG dbg
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const WmGemm g, const int tiles_n, const int tiles_m, const int dbg) {
+// DBG: ablation switches of scripts/gemm_ablate.py (1 no operand loads, 2 no MFMAs, 4 no epilogue) as a TEMPLATE parameter: the
+// product instance is DBG = 0 and carries none of them; the other instances exist only in a -DWM_GEMM_ABLATE build
+#define WM_PP_DBG DBG
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const WmGemm g, const int tiles_n, const int tiles_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const WmGemm g, cons
     pb[q] = static_cast<const __bf16*>(g.B) + (int64_t)(n0 + 128 * q + lrow) * g.ldb + 8 * chunk;
   }
   auto request = [&](int stage) {
-    if (dbg & 1) return;                                         // (ablation: no operand loads)
+    if constexpr (DBG & 1) return;                               // (ablation: no operand loads)
     char* t = smem + (stage & 3) * STAGE_B + 16 * wave * 64;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const WmGemm g, cons
   }
 #undef WM_NT_FRAGS
   __builtin_amdgcn_s_barrier();                                  // b_(S+1): nobody reads an operand stage any more
-  if (dbg & 4) {                                                 // (ablation: no epilogue; keep the accumulators alive)
+  if constexpr (DBG & 4) {                                       // (ablation: no epilogue; keep the accumulators alive)
     if (acc[0][0][0] == 12345.678f) static_cast<float*>(g.C)[0] = acc[3][1][15] + acc[1][0][3];
     return;
   }
@@ -313,18 +315,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const WmGemm g, cons
   }
 }
 
-template <int EPI>
+template <int EPI, int DBG = 0>
 int launch_nt_pp(const WmGemm& g, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<EPI, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
     attr = true;
   }
   const int tiles_n = g.N / 256, tiles_m = (g.M + 255) / 256;
   wm_gemm_family_tls = WM_FAM_NT_PP;
-  const char* d = getenv("WM_GEMM_DBG");                          // ablation switches for scripts/gemm_ablate.py (0 in the product)
-  hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI>), dim3(8 * ((tiles_m + 7) / 8) * tiles_n), dim3(512), SMEM_B, st, g, tiles_n, tiles_m,
-                     d ? atoi(d) : 0);
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, DBG>), dim3(8 * ((tiles_m + 7) / 8) * tiles_n), dim3(512), SMEM_B, st, g, tiles_n, tiles_m);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
@@ -333,6 +333,19 @@ int launch_nt_pp(const WmGemm& g, hipStream_t st) {
 
 // launchers for gemm_big.hip's dispatch (which has checked shapes and alignment)
 int wm_gemm_pp_nt_launch(const WmGemm& g, int epi, hipStream_t st) {
+#ifdef WM_GEMM_ABLATE                                             // bench-only build (make ABLATE=1): WM_GEMM_DBG picks an ablated instance of EPI 0
+  if (const char* d = getenv("WM_GEMM_DBG"); d && epi == 0) {
+    switch (atoi(d)) {
+      case 1: return launch_nt_pp<0, 1>(g, st);
+      case 2: return launch_nt_pp<0, 2>(g, st);
+      case 3: return launch_nt_pp<0, 3>(g, st);
+      case 4: return launch_nt_pp<0, 4>(g, st);
+      case 5: return launch_nt_pp<0, 5>(g, st);
+      case 6: return launch_nt_pp<0, 6>(g, st);
+      default: break;
+    }
+  }
+#endif
   return epi == 0 ? launch_nt_pp<0>(g, st) : epi == 1 ? launch_nt_pp<1>(g, st) : epi == 2 ? launch_nt_pp<2>(g, st) : launch_nt_pp<4>(g, st);
 }
 int wm_gemm_pp_tn_launch(const WmGemm& g, int klen, int tiles_n, int tiles_m, int ksplit, float* part, hipStream_t st) {

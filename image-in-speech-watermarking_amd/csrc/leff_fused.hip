@@ -15,6 +15,7 @@
 //             a workgroup walks.  Weights are staged as they lie and read with ds_read_b64_tr_b16 where the product wants
 //             them transposed.  ~30 C instead of 52 C.
 // fc1 / fc2 weight gradients stay on the TN GEMM (K = tokens): fc2's reads the saved h2 with GELU applied while staging.
+#include <type_traits>
 #include "common.h"
 #include "gelu_poly.h"
 #include "../../include/wm_kernels.h"
@@ -120,210 +121,301 @@ __device__ __forceinline__ void halo_store(__bf16* Xs, const u32x4 (&xr)[Cfg<C>:
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward
+// Persistent workgroups: each walks a contiguous range of tiles.  Nothing the next phase needs is requested at the moment it is
+// needed: the next hidden slice's W1 rows / depthwise taps / fc1 bias, the next tile's halo image and this tile's residual rows are
+// loaded into registers one phase (or one slice) ahead, so that a phase only waits for data requested a few microseconds earlier
+// (the first version loaded and stored in place: ~6 us per slice and workgroup, four fifths of it memory round trips).
+template <int C> struct FwdPre {                                       // next slice's operands, in flight
+  u32x4 w1[TCH * Cfg<C>::CPR / 256];
+  float wv[3], bv;
+};
+template <int C>
+__device__ __forceinline__ void fwd_prefetch(FwdPre<C>& p, const __bf16* __restrict__ w1, const float* __restrict__ b1,
+                                             const float* __restrict__ wd, const float* __restrict__ bd, int hb, int tid) {
+  typedef Cfg<C> K;
+#pragma unroll
+  for (int k = 0; k < TCH * K::CPR / 256; ++k) {
+    const int idx = tid + 256 * k, row = idx / K::CPR, part = idx - row * K::CPR;
+    p.w1[k] = *reinterpret_cast<const u32x4*>(w1 + (int64_t)(hb + row) * C + part * 8);
+  }
+  // depthwise weights of the slice: 576 consecutive floats [channel][tap] (coalesced), biases behind them
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = tid + 256 * k;
+    p.wv[k] = i < 9 * TCH ? wd[hb * 9 + i] : bd[hb + (i < 10 * TCH ? i - 9 * TCH : 0)];
+  }
+  p.bv = b1[hb + (tid & 63)];
+}
+template <int C>
+__device__ __forceinline__ void fwd_stage(const FwdPre<C>& p, __bf16* Ws, float* wl, float* b1s, int tid) {
+  typedef Cfg<C> K;
+#pragma unroll
+  for (int k = 0; k < TCH * K::CPR / 256; ++k) {
+    const int idx = tid + 256 * k, row = idx / K::CPR, part = idx - row * K::CPR;
+    *reinterpret_cast<u32x4*>(Ws + row * K::XS + part * 8) = p.w1[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (tid + 256 * k < 10 * TCH) wl[tid + 256 * k] = p.wv[k];        // [channel][9] as it lies, then the 64 biases
+  if (tid < TCH) b1s[tid] = p.bv;
+}
+
 template <int C, bool SAVE>
-__global__ __launch_bounds__(256) void leff_fwd_kernel(const __bf16* __restrict__ xn2, const float* __restrict__ x1,
+__global__ __launch_bounds__(256, 2) void leff_fwd_kernel(const __bf16* __restrict__ xn2, const float* __restrict__ x1,
                                                        const __bf16* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ wd, const float* __restrict__ bd,
                                                        const __bf16* __restrict__ w2, const float* __restrict__ b2,
                                                        const float* __restrict__ s2, float* __restrict__ x2,
-                                                       __bf16* __restrict__ h1, __bf16* __restrict__ h2, int B, int hw) {
+                                                       __bf16* __restrict__ h1, __bf16* __restrict__ h2, int B, int hw,
+                                                       int ntiles, int per) {
   typedef Cfg<C> K;
   extern __shared__ __attribute__((aligned(16))) char smem[];        // one array (> 64 KB at C = 128: dynamic allocation)
   __bf16* const Xs = reinterpret_cast<__bf16*>(smem);                 // LayerNorm output, tile + halo (operand of fc1)
   __bf16* const Ws = Xs + NPIX * K::XS;                               // W1 slice, then W2 slice
   __bf16* const A1s = Ws + K::WS_EL;                                  // h1 slice, then gelu(h1) (zero outside the image)
   __bf16* const A2s = A1s + NPIX * HS;                                // gelu(h2): A operand of fc2
-  float* const wl = reinterpret_cast<float*>(A2s + 64 * HS);          // depthwise weights [tap][channel], row 9 = bias
+  float* const wl = reinterpret_cast<float*>(A2s + 64 * HS);          // depthwise weights [channel][tap], then the 64 biases
   float* const b1s = wl + 10 * TCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int nt = hw / TP;
-  const int t = virtual_block(blockIdx.x, gridDim.x);                 // neighbouring tiles (shared halo rows) on one XCD
-  const int b = t / (nt * nt), tr_ = t - b * nt * nt, ty = tr_ / nt, tx = tr_ - ty * nt;
-  const int Ch = 4 * C;
+  const int nt = hw / TP, Ch = 4 * C;
+  const int c2 = tid & 31, py = tid >> 5;                             // depthwise stage: two channels of one tile row
+  constexpr bool EARLY = C <= 64;                                     // when the next tile's image / this tile's residual are requested
+  const int t0 = blockIdx.x * per, t1 = min(ntiles, t0 + per);       // consecutive tiles: neighbours share halo columns in L2
+  if (t0 >= t1) return;
+  auto tile_pos = [&](int t, int& b, int& ty, int& tx) {
+    b = t / (nt * nt);
+    const int tr_ = t - b * nt * nt;
+    ty = tr_ / nt;
+    tx = tr_ - ty * nt;
+  };
 
   u32x4 xr[K::NXL];
-  halo_load<C, __bf16>(xr, xn2, b, ty, tx, hw, tid);
-  halo_store<C>(Xs, xr, ty, tx, hw, tid);
+  FwdPre<C> pre;
+  int b, ty, tx;
+  tile_pos(t0, b, ty, tx);
+  if constexpr (EARLY) halo_load<C, __bf16>(xr, xn2, b, ty, tx, hw, tid);
+  fwd_prefetch<C>(pre, w1, b1, wd, bd, 0, tid);
+  for (int t = t0; t < t1; ++t) {
+    tile_pos(t, b, ty, tx);
+    if constexpr (!EARLY) halo_load<C, __bf16>(xr, xn2, b, ty, tx, hw, tid);
+    halo_store<C>(Xs, xr, ty, tx, hw, tid);                           // (every reader of the previous tile's image is behind a barrier)
+    f32x16 acc2[K::NTW];
+#pragma unroll
+    for (int i = 0; i < K::NTW; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
+    const int64_t row0 = (((int64_t)b * hw + ty * TP + py) * hw + tx * TP) * Ch + 2 * c2;
+    float res[K::NTW][16];                                            // x1 of this tile in accumulator layout, requested in the last slice
 
-  f32x16 acc2[K::NTW];
-#pragma unroll
-  for (int i = 0; i < K::NTW; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
-  const int c2 = tid & 31, py = tid >> 5;                             // depthwise stage: two channels of one tile row
-  const int64_t row0 = (((int64_t)b * hw + ty * TP + py) * hw + tx * TP) * Ch + 2 * c2;
-
-  for (int kc = 0; kc < K::NCH; ++kc) {
-    const int hb = kc * TCH;
-    {                                                                 // W1 slice [64][C], depthwise weights, fc1 bias
-      constexpr int NL = TCH * K::CPR / 256;
-      u32x4 wreg[NL];
-#pragma unroll
-      for (int k = 0; k < NL; ++k) {
-        const int idx = tid + 256 * k, row = idx / K::CPR, part = idx - row * K::CPR;
-        wreg[k] = *reinterpret_cast<const u32x4*>(w1 + (int64_t)(hb + row) * C + part * 8);
-      }
-      float wv[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        int i = tid + 256 * k;
-        i = i < 10 * TCH ? i : 10 * TCH - 1;
-        const int kk = i >> 6, c = i & 63;
-        wv[k] = kk < 9 ? wd[(hb + c) * 9 + kk] : bd[hb + c];
-      }
-      const float bv = b1[hb + (tid & 63)];
-#pragma unroll
-      for (int k = 0; k < NL; ++k) {
-        const int idx = tid + 256 * k, row = idx / K::CPR, part = idx - row * K::CPR;
-        *reinterpret_cast<u32x4*>(Ws + row * K::XS + part * 8) = wreg[k];
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        if (tid + 256 * k < 10 * TCH) wl[tid + 256 * k] = wv[k];
-      if (tid < TCH) b1s[tid] = bv;
-    }
-    __syncthreads();
-    // W2 slice [C][64] into registers: lands while fc1 runs
-    u32x4 w2r[C / 32];
-#pragma unroll
-    for (int k = 0; k < C / 32; ++k) {
-      const int idx = tid + 256 * k, n = idx >> 3, part = idx & 7;
-      w2r[k] = *reinterpret_cast<const u32x4*>(w2 + (int64_t)n * Ch + hb + part * 8);
-    }
-    {                                                                 // fc1: h1[hidden][pixel] = W1 slice . xn2^T
-      const int pix = 32 * wave + r;
-      const int prow = pix < NPIX ? pix : NPIX - 1;
-      f32x16 a[2];
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) a[ct][e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < C / 16; ++ks) {
-        const bf16x8 bfrag = row_frag<K::XS>(Xs, prow, ks, h);
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-          a[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<K::XS>(Ws, 32 * ct + r, ks, h), bfrag, a[ct], 0, 0, 0);
-      }
-      if (pix < NPIX) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int hid = 32 * ct + 8 * g + 4 * h;
-            const float4 bb = *reinterpret_cast<const float4*>(b1s + hid);
-            *reinterpret_cast<uint2*>(A1s + pix * HS + hid) =
-                pack4(a[ct][4 * g] + bb.x, a[ct][4 * g + 1] + bb.y, a[ct][4 * g + 2] + bb.z, a[ct][4 * g + 3] + bb.w);
-          }
-      }
-    }
-    __syncthreads();
-    {                                                                 // h1 out (centre pixels), GELU in place; W2 slice -> LDS
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int idx = tid + 256 * k;
-        if (idx < NPIX * 8) {
-          const int pix = idx >> 3, part = idx & 7;
-          const Pix p(pix, ty, tx, hw);
-          __bf16* cell = A1s + pix * HS + part * 8;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(cell);
-          if (SAVE && p.centre)
-            stream_store(h1 + (((int64_t)b * hw + p.gy) * hw + p.gx) * Ch + hb + part * 8, make_uint4(v.x, v.y, v.z, v.w));
-          u32x4 o;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            f32x2 av, gv;
-            gelu_pair<__bf16>(up2(v[i]), av, gv);
-            o[i] = p.inb ? pack_bf2(av.x, av.y) : 0u;                 // the convolution pads gelu(h1) with zeros
-          }
-          *reinterpret_cast<u32x4*>(cell) = o;
-        }
-      }
+    // one hidden slice; LAST (compile-time) = the tile's last slice, which also requests the next tile's image and this tile's
+    // residual rows: as a run-time condition inside one loop those registers would be live through every slice
+    auto slice = [&](const int kc, auto last_c) {
+      constexpr bool LAST = decltype(last_c)::value;
+      const int hb = kc * TCH;
+      fwd_stage<C>(pre, Ws, wl, b1s, tid);
+      __syncthreads();
+      // W2 slice [C][64] into registers: lands while fc1 runs
+      u32x4 w2r[C / 32];
 #pragma unroll
       for (int k = 0; k < C / 32; ++k) {
         const int idx = tid + 256 * k, n = idx >> 3, part = idx & 7;
-        *reinterpret_cast<u32x4*>(Ws + n * HS + part * 8) = w2r[k];
+        w2r[k] = *reinterpret_cast<const u32x4*>(w2 + (int64_t)n * Ch + hb + part * 8);
       }
-    }
-    __syncthreads();
-    {                                                                 // depthwise 3 x 3, second GELU
-      f32x2 wr[9], br;
+      {                                                               // fc1: h1[hidden][pixel] = W1 slice . xn2^T
+        const int pix = 32 * wave + r;
+        const int prow = pix < NPIX ? pix : NPIX - 1;
+        f32x16 a[2];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) wr[k] = *reinterpret_cast<const f32x2*>(wl + k * TCH + 2 * c2);
-      br = *reinterpret_cast<const f32x2*>(wl + 9 * TCH + 2 * c2);
-      auto at = [&](int dy, int x) { return up2(*reinterpret_cast<const uint32_t*>(A1s + ((py + dy) * HP + x) * HS + 2 * c2)); };
-      f32x2 col[3][3];                                                // col[x % 3][dy]
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int x = 0; x < 2; ++x)
+          for (int e = 0; e < 16; ++e) a[ct][e] = 0.f;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) col[x][dy] = at(dy, x);
+        for (int ks = 0; ks < C / 16; ++ks) {
+          const bf16x8 bfrag = row_frag<K::XS>(Xs, prow, ks, h);
 #pragma unroll
-      for (int px = 0; px < TP; ++px) {
+          for (int ct = 0; ct < 2; ++ct)
+            a[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<K::XS>(Ws, 32 * ct + r, ks, h), bfrag, a[ct], 0, 0, 0);
+        }
+        if (pix < NPIX) {
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) col[(px + 2) % 3][dy] = at(dy, px + 2);
-        f32x2 o = br;
+          for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) o += wr[dy * 3 + dx] * col[(px + dx) % 3][dy];
-        if (SAVE) stream_store(h2 + row0 + (int64_t)px * Ch + hb, pack_bf2(o.x, o.y));
-        f32x2 av, gv;
-        gelu_pair<__bf16>(o, av, gv);
-        *reinterpret_cast<uint32_t*>(A2s + (py * TP + px) * HS + 2 * c2) = pack_bf2(av.x, av.y);
+            for (int g = 0; g < 4; ++g) {
+              const int hid = 32 * ct + 8 * g + 4 * h;
+              const float4 bb = *reinterpret_cast<const float4*>(b1s + hid);
+              *reinterpret_cast<uint2*>(A1s + pix * HS + hid) =
+                  pack4(a[ct][4 * g] + bb.x, a[ct][4 * g + 1] + bb.y, a[ct][4 * g + 2] + bb.z, a[ct][4 * g + 3] + bb.w);
+            }
+        }
       }
-    }
-    __syncthreads();
+      __syncthreads();
+      // the next slice's operands (slice 0 again behind the last one: the next tile's), the next tile's image and this tile's
+      // residual rows are requested here and used a slice / an epilogue later
+      fwd_prefetch<C>(pre, w1, b1, wd, bd, kc + 1 < K::NCH ? hb + TCH : 0, tid);
+      auto tile_prefetch = [&]() {
+        if constexpr (EARLY) {                                         // (C = 128: 28 registers too many; the image is loaded at the tile's top)
+          int nb, nty, ntx;
+          tile_pos(t + 1 < t1 ? t + 1 : t, nb, nty, ntx);
+          halo_load<C, __bf16>(xr, xn2, nb, nty, ntx, hw, tid);
+        }
 #pragma unroll
-    for (int i = 0; i < K::NTW; ++i) {                                // fc2: x2[token][channel] += gelu(h2) . W2 slice^T
+        for (int i = 0; i < K::NTW; ++i) {
+          const int tile = wave + 4 * i;
+          const int rt = tile & 1, ct = (tile < K::NT ? tile : 0) >> 1;
+          const float* xrow = x1 + (((int64_t)b * hw + ty * TP + 4 * rt + (h >> 0) * 0) * hw + tx * TP) * C + 32 * ct + r;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int tok = mma32_row(e, h);                          // token 32 rt + tok: tile row 4 rt + (tok >> 3), column tok & 7
+            res[i][e] = xrow[((tok >> 3) * hw + (tok & 7)) * C];
+          }
+        }
+      };
+      if constexpr (EARLY && LAST) tile_prefetch();
+      {                                                               // h1 out (centre pixels), GELU in place; W2 slice -> LDS
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int idx = tid + 256 * k;
+          if (idx < NPIX * 8) {
+            const int pix = idx >> 3, part = idx & 7;
+            const Pix p(pix, ty, tx, hw);
+            __bf16* cell = A1s + pix * HS + part * 8;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(cell);
+            if (SAVE && p.centre)
+              stream_store(h1 + (((int64_t)b * hw + p.gy) * hw + p.gx) * Ch + hb + part * 8, make_uint4(v.x, v.y, v.z, v.w));
+            u32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              f32x2 av, gv;
+              gelu_pair<__bf16>(up2(v[i]), av, gv);
+              o[i] = p.inb ? pack_bf2(av.x, av.y) : 0u;               // the convolution pads gelu(h1) with zeros
+            }
+            *reinterpret_cast<u32x4*>(cell) = o;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < C / 32; ++k) {
+          const int idx = tid + 256 * k, n = idx >> 3, part = idx & 7;
+          *reinterpret_cast<u32x4*>(Ws + n * HS + part * 8) = w2r[k];
+        }
+      }
+      __syncthreads();
+      {                                                               // depthwise 3 x 3, second GELU
+        f32x2 wr[9], br;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wr[k] = (f32x2){wl[(2 * c2) * 9 + k], wl[(2 * c2 + 1) * 9 + k]};
+        br = *reinterpret_cast<const f32x2*>(wl + 9 * TCH + 2 * c2);
+        auto at = [&](int dy, int x) { return up2(*reinterpret_cast<const uint32_t*>(A1s + ((py + dy) * HP + x) * HS + 2 * c2)); };
+        f32x2 col[3][3];                                              // col[x % 3][dy]
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) col[x][dy] = at(dy, x);
+#pragma unroll
+        for (int px = 0; px < TP; ++px) {
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) col[(px + 2) % 3][dy] = at(dy, px + 2);
+          f32x2 o = br;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) o += wr[dy * 3 + dx] * col[(px + dx) % 3][dy];
+          if (SAVE) stream_store(h2 + row0 + (int64_t)px * Ch + hb, pack_bf2(o.x, o.y));
+          f32x2 av, gv;
+          gelu_pair<__bf16>(o, av, gv);
+          *reinterpret_cast<uint32_t*>(A2s + (py * TP + px) * HS + 2 * c2) = pack_bf2(av.x, av.y);
+        }
+      }
+      __syncthreads();
+      (void)tile_prefetch;
+#pragma unroll
+      for (int i = 0; i < K::NTW; ++i) {                              // fc2: x2[token][channel] += gelu(h2) . W2 slice^T
+        const int tile = wave + 4 * i;
+        if (tile < K::NT) {
+          const int rt = tile & 1, ct = tile >> 1;
+#pragma unroll
+          for (int ks = 0; ks < TCH / 16; ++ks)
+            acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HS>(A2s, 32 * rt + r, ks, h),
+                                                              row_frag<HS>(Ws, 32 * ct + r, ks, h), acc2[i], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    };
+    for (int kc = 0; kc < K::NCH - 1; ++kc) slice(kc, std::false_type{});
+    slice(K::NCH - 1, std::true_type{});
+    // (acc + b2) * DropPath + x1: a lane owns one channel, the 16 accumulator registers are 16 tokens
+    const float sc = s2 ? s2[b] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < K::NTW; ++i) {
       const int tile = wave + 4 * i;
       if (tile < K::NT) {
-        const int rt = tile & 1, ct = tile >> 1;
+        const int rt = tile & 1, ct = tile >> 1, ch = 32 * ct + r;
+        const float bias = b2[ch];
+        float* orow = x2 + (((int64_t)b * hw + ty * TP + 4 * rt) * hw + tx * TP) * C + ch;
 #pragma unroll
-        for (int ks = 0; ks < TCH / 16; ++ks)
-          acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HS>(A2s, 32 * rt + r, ks, h),
-                                                            row_frag<HS>(Ws, 32 * ct + r, ks, h), acc2[i], 0, 0, 0);
+        for (int e = 0; e < 16; ++e) {
+          const int tok = mma32_row(e, h);
+          const int64_t o_ = (int64_t)((tok >> 3) * hw + (tok & 7)) * C;
+          float rv;
+          if constexpr (EARLY) rv = res[i][e];
+          else rv = x1[(orow - x2) + o_];                             // C = 128: no registers for an early request (8 slices per tile amortise it)
+          __builtin_nontemporal_store((acc2[i][e] + bias) * sc + rv, orow + o_);
+        }
       }
-    }
-    __syncthreads();
-  }
-  // (acc + b2) * DropPath + x1: a lane owns one channel, the 16 accumulator registers are 16 tokens
-  const float sc = s2 ? s2[b] : 1.0f;
-#pragma unroll
-  for (int i = 0; i < K::NTW; ++i) {
-    const int tile = wave + 4 * i;
-    if (tile < K::NT) {
-      const int rt = tile & 1, ct = tile >> 1, ch = 32 * ct + r;
-      const float bias = b2[ch];
-      float res[16];
-      int64_t off[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int tok = 32 * rt + mma32_row(e, h);
-        off[e] = (((int64_t)b * hw + ty * TP + (tok >> 3)) * hw + tx * TP + (tok & 7)) * C + ch;
-        res[e] = x1[off[e]];
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) __builtin_nontemporal_store((acc2[i][e] + bias) * sc + res[e], x2 + off[e]);
     }
   }
 }
 
 // ----------------------------------------------------------------------------------------------------------- backward
 // One workgroup walks the strip of tiles (b, ty, *); dw / db of the depthwise convolution are summed in LDS over the strip.
+// As in the forward kernel, a slice's operands (W2 rows, the saved h2 halo slice, h1 of the thread's pixels, the depthwise taps)
+// are requested one slice ahead, the W1 rows one phase ahead and the next tile's gradient image during the tile's last slice.
+template <int C> struct BwdPre {
+  u32x4 w2[C / 32], h2[4];
+  uint32_t hv[TP];
+  float wv[3];
+};
+template <int C>
+__device__ __forceinline__ void bwd_prefetch(BwdPre<C>& p, const __bf16* __restrict__ h1, const __bf16* __restrict__ h2,
+                                             const float* __restrict__ wd, const __bf16* __restrict__ w2, int b, int ty, int tx,
+                                             int hw, int hb, int64_t row0, int tid) {
+  const int Ch = 4 * C;
+#pragma unroll
+  for (int k = 0; k < C / 32; ++k) {
+    const int idx = tid + 256 * k, n = idx >> 3, part_ = idx & 7;
+    p.w2[k] = *reinterpret_cast<const u32x4*>(w2 + (int64_t)n * Ch + hb + part_ * 8);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int idx = tid + 256 * k;
+    idx = idx < NPIX * 8 ? idx : NPIX * 8 - 1;
+    const int pix = idx >> 3, part_ = idx & 7;
+    const Pix q(pix, ty, tx, hw);
+    const int cy = min(max(q.gy, 0), hw - 1), cx = min(max(q.gx, 0), hw - 1);
+    p.h2[k] = *reinterpret_cast<const u32x4*>(h2 + (((int64_t)b * hw + cy) * hw + cx) * Ch + hb + part_ * 8);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = tid + 256 * k;
+    p.wv[k] = wd[hb * 9 + (i < 9 * TCH ? i : 0)];                     // [channel][tap] as it lies: 576 consecutive floats
+  }
+#pragma unroll
+  for (int px = 0; px < TP; ++px) p.hv[px] = *reinterpret_cast<const uint32_t*>(h1 + row0 + (int64_t)px * Ch + hb);
+}
+
 template <int C, typename DT>
-__global__ __launch_bounds__(256) void leff_bwd_kernel(const DT* __restrict__ dy, const float* __restrict__ s2,
-                                                       const __bf16* __restrict__ h1, const __bf16* __restrict__ h2,
-                                                       const __bf16* __restrict__ w1, const float* __restrict__ wd,
-                                                       const __bf16* __restrict__ w2, __bf16* __restrict__ dh1,
-                                                       __bf16* __restrict__ dxn2, float* __restrict__ dwd,
-                                                       float* __restrict__ dbd, float* __restrict__ part, int B, int hw) {
+__global__ __launch_bounds__(256, 2) void leff_bwd_kernel(const DT* __restrict__ dy, const float* __restrict__ s2,
+                                                          const __bf16* __restrict__ h1, const __bf16* __restrict__ h2,
+                                                          const __bf16* __restrict__ w1, const float* __restrict__ wd,
+                                                          const __bf16* __restrict__ w2, __bf16* __restrict__ dh1,
+                                                          __bf16* __restrict__ dxn2, float* __restrict__ dwd,
+                                                          float* __restrict__ dbd, float* __restrict__ part, int B, int hw) {
   typedef Cfg<C> K;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* const DYs = reinterpret_cast<__bf16*>(smem);                // incoming gradient, tile + halo; then the dxn2 tile
   __bf16* const Ws = DYs + NPIX * K::XS;                              // W2 slice [C][64] as it lies, then W1 slice [64][C]
   __bf16* const DH2s = Ws + K::WS_EL;                                 // h2 slice, then dh2 = (dy W2) gelu'(h2)
   __bf16* const DH1s = DH2s + NPIX * HS;                              // dh1: operand of dxn2 += dh1 W1
-  float* const wl = reinterpret_cast<float*>(DH1s + 64 * HS);
+  float* const wl = reinterpret_cast<float*>(DH1s + 64 * HS);         // depthwise taps [channel][9]
   float* const RED = wl + 9 * TCH;                                    // per-wave sums of the slice's dw / db
   float* const ACC = RED + 4 * 10 * TCH;                              // [slice][tap | bias][channel] over the strip
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -332,64 +424,45 @@ __global__ __launch_bounds__(256) void leff_bwd_kernel(const DT* __restrict__ dy
   const int b = strip / nt, ty = strip - b * nt;
   const int Ch = 4 * C;
   const int c2 = tid & 31, py = tid >> 5;
+  constexpr bool EARLY = C <= 64;                                     // the next tile's gradient image is requested a slice ahead
   const float sc = s2 ? s2[b] : 1.0f;
   for (int i = tid; i < K::NCH * 10 * TCH; i += 256) ACC[i] = 0.f;
+  const int64_t strip0 = (((int64_t)b * hw + ty * TP + py) * hw) * Ch + 2 * c2;
 
+  u32x4 xr[K::NXL];
+  BwdPre<C> pre;
+  if constexpr (EARLY) halo_load<C, DT>(xr, dy, b, ty, 0, hw, tid);
+  bwd_prefetch<C>(pre, h1, h2, wd, w2, b, ty, 0, hw, 0, strip0, tid);
   for (int tx = 0; tx < nt; ++tx) {
-    {
-      u32x4 xr[K::NXL];
-      halo_load<C, DT>(xr, dy, b, ty, tx, hw, tid);
-      halo_store<C>(DYs, xr, ty, tx, hw, tid);
-    }
+    if constexpr (!EARLY) halo_load<C, DT>(xr, dy, b, ty, tx, hw, tid);
+    halo_store<C>(DYs, xr, ty, tx, hw, tid);
     f32x16 acc2[K::NTW];
 #pragma unroll
     for (int i = 0; i < K::NTW; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
-    const int64_t row0 = (((int64_t)b * hw + ty * TP + py) * hw + tx * TP) * Ch + 2 * c2;
+    const int64_t row0 = strip0 + (int64_t)tx * TP * Ch;
+    const int txn = tx + 1 < nt ? tx + 1 : tx;
 
-    for (int kc = 0; kc < K::NCH; ++kc) {
+    auto slice = [&](const int kc, auto last_c) {
+      constexpr bool LAST = decltype(last_c)::value;
       const int hb = kc * TCH;
       uint32_t hv[TP];                                                // h1 of this thread's 8 pixels x 2 channels
-      {                                                               // W2 slice as it lies, h2 halo slice, depthwise weights
-        u32x4 wreg[C / 32], hreg[4];
 #pragma unroll
-        for (int k = 0; k < C / 32; ++k) {
-          const int idx = tid + 256 * k, n = idx >> 3, part_ = idx & 7;
-          wreg[k] = *reinterpret_cast<const u32x4*>(w2 + (int64_t)n * Ch + hb + part_ * 8);
-        }
+      for (int px = 0; px < TP; ++px) hv[px] = pre.hv[px];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          int idx = tid + 256 * k;
-          idx = idx < NPIX * 8 ? idx : NPIX * 8 - 1;
-          const int pix = idx >> 3, part_ = idx & 7;
-          const Pix p(pix, ty, tx, hw);
-          const int cy = min(max(p.gy, 0), hw - 1), cx = min(max(p.gx, 0), hw - 1);
-          hreg[k] = *reinterpret_cast<const u32x4*>(h2 + (((int64_t)b * hw + cy) * hw + cx) * Ch + hb + part_ * 8);
-        }
-        float wv[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          int i = tid + 256 * k;
-          i = i < 9 * TCH ? i : 9 * TCH - 1;
-          wv[k] = wd[(hb + (i & 63)) * 9 + (i >> 6)];
-        }
-#pragma unroll
-        for (int px = 0; px < TP; ++px) hv[px] = *reinterpret_cast<const uint32_t*>(h1 + row0 + (int64_t)px * Ch + hb);
-#pragma unroll
-        for (int k = 0; k < C / 32; ++k) {
-          const int idx = tid + 256 * k, n = idx >> 3, part_ = idx & 7;
-          *reinterpret_cast<u32x4*>(Ws + n * HS + part_ * 8) = wreg[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int idx = tid + 256 * k;
-          if (idx < NPIX * 8) *reinterpret_cast<u32x4*>(DH2s + (idx >> 3) * HS + (idx & 7) * 8) = hreg[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (tid + 256 * k < 9 * TCH) wl[tid + 256 * k] = wv[k];
+      for (int k = 0; k < C / 32; ++k) {                              // W2 slice as it lies, h2 halo slice, depthwise taps
+        const int idx = tid + 256 * k, n = idx >> 3, part_ = idx & 7;
+        *reinterpret_cast<u32x4*>(Ws + n * HS + part_ * 8) = pre.w2[k];
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k;
+        if (idx < NPIX * 8) *reinterpret_cast<u32x4*>(DH2s + (idx >> 3) * HS + (idx & 7) * 8) = pre.h2[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (tid + 256 * k < 9 * TCH) wl[tid + 256 * k] = pre.wv[k];
       __syncthreads();
       // W1 slice [64][C] into registers: lands while the first product runs
       constexpr int NL1 = TCH * K::CPR / 256;
@@ -435,11 +508,18 @@ __global__ __launch_bounds__(256) void leff_bwd_kernel(const DT* __restrict__ dy
         const int idx = tid + 256 * k, row = idx / K::CPR, part_ = idx - row * K::CPR;
         *reinterpret_cast<u32x4*>(Ws + row * K::XS + part_ * 8) = w1r[k];
       }
+      // the next slice's operands (behind the last slice: slice 0 of the next tile) and, in the last slice, the next tile's image
+      if constexpr (LAST) {
+        bwd_prefetch<C>(pre, h1, h2, wd, w2, b, ty, txn, hw, 0, strip0 + (int64_t)txn * TP * Ch, tid);
+        if constexpr (EARLY) halo_load<C, DT>(xr, dy, b, ty, txn, hw, tid);
+      } else {
+        bwd_prefetch<C>(pre, h1, h2, wd, w2, b, ty, tx, hw, hb + TCH, row0, tid);
+      }
       {                                                               // transposed depthwise conv, gelu'(h1); dw / db sums
         f32x2 wr[9], aw[9], ab = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-          wr[k] = *reinterpret_cast<const f32x2*>(wl + k * TCH + 2 * c2);
+          wr[k] = (f32x2){wl[(2 * c2) * 9 + k], wl[(2 * c2 + 1) * 9 + k]};
           aw[k] = (f32x2){0.f, 0.f};
         }
         auto at = [&](int rr, int x) { return up2(*reinterpret_cast<const uint32_t*>(DH2s + ((py + rr) * HP + x) * HS + 2 * c2)); };
@@ -498,7 +578,9 @@ __global__ __launch_bounds__(256) void leff_bwd_kernel(const DT* __restrict__ dy
       for (int i = tid; i < 10 * TCH; i += 256)
         ACC[kc * 10 * TCH + i] += (RED[i] + RED[10 * TCH + i]) + (RED[2 * 10 * TCH + i] + RED[3 * 10 * TCH + i]);
       __syncthreads();
-    }
+    };
+    for (int kc = 0; kc < K::NCH - 1; ++kc) slice(kc, std::false_type{});
+    slice(K::NCH - 1, std::true_type{});
     // dxn2 tile: [channel on the registers][token on the lane] -> LDS [token][C] -> 16-byte rows
 #pragma unroll
     for (int i = 0; i < K::NTW; ++i) {
@@ -521,7 +603,8 @@ __global__ __launch_bounds__(256) void leff_bwd_kernel(const DT* __restrict__ dy
     }
     __syncthreads();
   }
-  // the strip's dw [Ch][9] / db [Ch] as part[strip][Ch][10] (summed by the deferred reduction), or atomics without scratch
+  // the strip's dw [Ch][9] / db [Ch] as part[strip][Ch][10] (summed by the deferred reduction), or atomics without scratch;
+  // ACC holds [slice][tap | bias][channel], the slices' taps lie [channel][9] in wl but were summed tap-major
   for (int i = tid; i < Ch * 10; i += 256) {
     const int ch = i / 10, k = i - ch * 10;
     const float v = ACC[(ch >> 6) * 10 * TCH + k * TCH + (ch & 63)];
@@ -532,6 +615,9 @@ __global__ __launch_bounds__(256) void leff_bwd_kernel(const DT* __restrict__ dy
 }
 
 bool ok(int B, int hw, int C) { return B > 0 && hw >= 8 && (hw & 7) == 0 && (C == 32 || C == 64 || C == 128); }
+
+// resident workgroups per CU (LDS and registers permitting): the persistent grid of the forward kernel
+template <int C> constexpr int fwd_wgs_per_cu() { return C == 32 ? 3 : 2; }
 
 template <int C>
 int launch_fwd(const void* xn2, const float* x1, const void* w1, const float* b1, const float* wd, const float* bd, const void* w2,
@@ -544,14 +630,19 @@ int launch_fwd(const void* xn2, const float* x1, const void* w1, const float* b1
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leff_fwd_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
     attr = true;
   }
+  // a contiguous range of tiles per workgroup; ranges of at most 8 tiles so that small launches still cover the chip
+  const int slots = 256 * fwd_wgs_per_cu<C>();
+  int per = (tiles + slots - 1) / slots;
+  per = per < 1 ? 1 : (per > 8 ? 8 : per);
+  const int grid = (tiles + per - 1) / per;
   if (h1 && h2)
-    hipLaunchKernelGGL((leff_fwd_kernel<C, true>), dim3(tiles), dim3(256), SM, st, static_cast<const __bf16*>(xn2), x1,
+    hipLaunchKernelGGL((leff_fwd_kernel<C, true>), dim3(grid), dim3(256), SM, st, static_cast<const __bf16*>(xn2), x1,
                        static_cast<const __bf16*>(w1), b1, wd, bd, static_cast<const __bf16*>(w2), b2, s2, x2,
-                       static_cast<__bf16*>(h1), static_cast<__bf16*>(h2), B, hw);
+                       static_cast<__bf16*>(h1), static_cast<__bf16*>(h2), B, hw, tiles, per);
   else
-    hipLaunchKernelGGL((leff_fwd_kernel<C, false>), dim3(tiles), dim3(256), SM, st, static_cast<const __bf16*>(xn2), x1,
+    hipLaunchKernelGGL((leff_fwd_kernel<C, false>), dim3(grid), dim3(256), SM, st, static_cast<const __bf16*>(xn2), x1,
                        static_cast<const __bf16*>(w1), b1, wd, bd, static_cast<const __bf16*>(w2), b2, s2, x2,
-                       static_cast<__bf16*>(nullptr), static_cast<__bf16*>(nullptr), B, hw);
+                       static_cast<__bf16*>(nullptr), static_cast<__bf16*>(nullptr), B, hw, tiles, per);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

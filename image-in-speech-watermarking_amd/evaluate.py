@@ -204,8 +204,15 @@ def _decode(model, c):
     return model.wm_decode(c) if hasattr(model, "wm_decode") else model.decode(c)
 
 
-def _reconstruct_audio_mode(audio_datas, watermark, model, attack, model_name, batch, seed):
-    """``data_mode='audio'`` (audio_test.py:581-583, :601-606, :665-670, :733-772): raw-sample clips [n, 1, 128, 128]."""
+def _reconstruct_audio_mode(audio_datas, watermark, model, attack, model_name, batch, seed, audio_scale="0", data_min=None,
+                            data_max=None):
+    """``data_mode='audio'`` (audio_test.py:581-583, :601-606, :665-670, :733-772): raw-sample clips [n, 1, 128, 128].  The encoded
+    clips go back to the audio value range exactly as in 'stft' mode (audio_test.py:559-571 sits in front of the data_mode
+    branches); the attacked samples are handed to the extractor as they are (:733-760 applies no forward scale)."""
+    from .dataprep import parse_audio_scale, _stats
+    mode = parse_audio_scale(audio_scale)
+    if mode is not None and mode[0] == "range" and (data_min is None or data_max is None):
+        raise ValueError("range-style audio_scale needs the training set's data_min / data_max (audio_test.py:567-571)")
     U = len(audio_datas)
     L, n, len_last = audio_datas[0][0].shape[-1], audio_datas[0][1].shape[0], int(audio_datas[0][2])
     if any(d[0].shape[-1] != L for d in audio_datas):
@@ -213,6 +220,12 @@ def _reconstruct_audio_mode(audio_datas, watermark, model, attack, model_name, b
     waves = torch.cat([d[0].reshape(1, -1) for d in audio_datas]).contiguous().float()
     msg = watermark.reshape(1, 1, 32, 32).float()
     enc, dec = _run_model(model, model_name, torch.cat([d[1] for d in audio_datas]).contiguous(), msg, batch)
+    if mode is not None and mode[0] == "range":                           # :567-571
+        enc = ops.range_map(enc, _stats(data_min, data_max, waves.device), mode[1], mode[2], inverse=True)
+    elif mode is not None and mode[0] == "factor":                        # :562-564
+        scaled = torch.empty_like(enc)
+        ops.axpbyz(scaled, 1.0 / mode[1], enc, 0.0, enc, enc.numel())
+        enc = scaled
     recon_audio = enc.reshape(U, n * 128 * 128)[:, :(n - 1) * 128 * 128 + len_last].contiguous()       # last clip trimmed
     audio_att = _attack(recon_audio, attack, seed)
     La = audio_att.shape[-1]
@@ -232,7 +245,8 @@ def reconstruct_audio_batch(audio_datas, watermark, model, n_fft=255, attack=Non
     from .dataprep import parse_audio_scale, _stats
     if data_mode == "audio":
         waves, recon_audio, audio_att, dec, dec_att, n, n_att = _reconstruct_audio_mode(audio_datas, watermark, model, attack,
-                                                                                        model_name, batch, seed)
+                                                                                        model_name, batch, seed, audio_scale,
+                                                                                        data_min, data_max)
         return _metrics(waves, recon_audio, audio_att, watermark, dec, dec_att, n, n_att)
     if data_mode != "stft" or n_fft != 255:
         raise ValueError("the MI355X evaluation path covers data_mode='stft' (n_fft=255, audio_test.py:594-600) and 'audio'; "

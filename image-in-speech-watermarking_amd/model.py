@@ -369,15 +369,21 @@ class UformerAudio(nn.Module):
             self._tjobs = (torch.tensor(rows, dtype=torch.int32, device=self._flat.device).contiguous(), len(rows), tile0)
         return self._tjobs
 
-    def _refresh_weight_copy(self):
+    def _refresh_weight_copy(self, transposed=True):
+        """bf16 copy of the arena (every forward), and the TRANSPOSED copies of the wide Linear weights, which only the backward's
+        dX products read: skipped for inference (wm_decode, feature_extract, forward under no_grad)."""
         if self.compute_mode != "bf16":
             return
         if self._flat_h is None or self._flat_h.device != self._flat.device:
             self._flat_h = torch.empty(self._flat.numel(), device=self._flat.device, dtype=torch.bfloat16)
-            self._flat_ht = torch.empty(self._flat.numel(), device=self._flat.device, dtype=torch.bfloat16)
+            self._flat_ht = None
         ops.cast_bf16(self._flat, self._flat_h, self._flat.numel())
+        if not transposed:
+            return
         jobs, njobs, tiles = self._transpose_jobs()
         if njobs:
+            if self._flat_ht is None or self._flat_ht.device != self._flat.device:
+                self._flat_ht = torch.empty(self._flat.numel(), device=self._flat.device, dtype=torch.bfloat16)
             ops.transpose_cast_jobs(self._flat, self._flat_ht, jobs, njobs, tiles)
 
     def _W(self, name):
@@ -391,8 +397,8 @@ class UformerAudio(nn.Module):
     def _WT(self, name):
         """Transposed bf16 copy [in, out] of a wide Linear weight (bf16 mode, C >= BIG_C), else None."""
         v = self._views[name]
-        if self.compute_mode != "bf16" or min(v.shape) < self.BIG_C:
-            return None
+        if self.compute_mode != "bf16" or min(v.shape) < self.BIG_C or self._flat_ht is None:
+            return None                                            # (no copy: the product reads the weight as it lies)
         off = (v.data_ptr() - self._flat.data_ptr()) // 4
         return self._flat_ht[off:off + v.numel()].view(v.shape[1], v.shape[0])
 
@@ -422,7 +428,7 @@ class UformerAudio(nn.Module):
         self._ensure_runtime(y.device)
         with torch.no_grad():
             B = y.shape[0]
-            self._refresh_weight_copy()
+            self._refresh_weight_copy(transposed=False)
             feat, _ = self._trunk_fwd("decoder_wm.", y.contiguous().float(), B, None, 0, extractor=True)
             return self._ae_decode_fwd(feat, B)[0]
 
@@ -760,7 +766,7 @@ class UformerAudio(nn.Module):
         if tuple(x.shape[1:]) != (2, 128, 128) or tuple(msg.shape) != (B, 1, 32, 32):
             raise ValueError("expected x [B,2,128,128] and message [B,1,32,32] (reference model.py:2384-2389)")
         scales = self._scales_for(B, train, keep_scales, dev)
-        self._refresh_weight_copy()
+        self._refresh_weight_copy(transposed=train or torch.is_grad_enabled())
         n_trunk = 2 * len(self.arch.trunk_blocks())
         n_dec = 2 * len(self.arch.dec_blocks())
         S = {}

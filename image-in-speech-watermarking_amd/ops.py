@@ -8,7 +8,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, check, ptr, WmGemm, WmConv, WmAttack, WmReduceJob, WmWaveAttack
+from ._lib import lib, check, ptr, WmGemm, WmConv, WmAttack, WmReduceJob, WmWaveAttack, WmKernelError
 
 MODE_FP32, MODE_BF16, MODE_SPLIT = 0, 1, 2      # SPLIT: fp32 storage, GEMMs as three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
 
@@ -59,8 +59,24 @@ def linear_fwd(x, w, bias, out, mode, a_op=0, res=None, rowscale=None, rows_per_
     shift): y = LayerNorm(out rows) * gamma + beta (+ modulator[window position]) written by the same launch."""
     M, K = x.shape
     N = w.shape[0]
+    if ln is not None:
+        # wm_gemm_ln_fusable answers for (M, N, K, mode) only; the launchers also want rows_per_scale / hw * hw to be multiples of the
+        # tile height when a DropPath scale / the modulator ride along.  A launch they decline (WM_EINVAL: nothing was written) runs as
+        # the plain product followed by the LayerNorm kernel: same result, one more launch
+        try:
+            gemm(x, w, out, M, N, K, K, K, N, 1, 1, a_op=a_op, bias=bias, res=res, ldr=N, rowscale=rowscale,
+                 rows_per_scale=rows_per_scale, mode=mode, ln=ln)
+            return
+        except WmKernelError as e:
+            if e.code != 22:
+                raise
+        gamma, beta, mod, y, mean, rstd, hw, shift = ln
+        gemm(x, w, out, M, N, K, K, K, N, 1, 1, a_op=a_op, bias=bias, res=res, ldr=N, rowscale=rowscale,
+             rows_per_scale=rows_per_scale, mode=mode)
+        layernorm_fwd(out, gamma, beta, mod, y, mean, rstd, hw, shift)
+        return
     gemm(x, w, out, M, N, K, K, K, N, 1, 1, a_op=a_op, bias=bias, res=res, ldr=N, rowscale=rowscale,
-         rows_per_scale=rows_per_scale, mode=mode, ln=ln)
+         rows_per_scale=rows_per_scale, mode=mode)
 
 
 def linear_bwd_input(dy, w, dx, mode, rowscale=None, rows_per_scale=0, gaux=None, gaux_raw=False, wT=None):

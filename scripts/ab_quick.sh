@@ -1,0 +1,16 @@
+#!/bin/bash
+# Quick interleaved A/B of one environment toggle at the bench batch: bash scripts/ab_quick.sh VAR [rounds] [extra bench args]
+V=$1; R=${2:-2}; shift; shift
+QUIET="--no-cpu-baseline --no-kernel-timing --no-identity-leg --no-parity-mode-leg --no-secondary-legs --ber-train-steps 0"
+for r in $(seq 1 $R); do
+  for on in 0 1; do
+    if [ $on = 1 ]; then export $V=1; else unset $V; fi
+    python bench.py --steps 10 --warmup 3 $QUIET "$@" 2>/tmp/ab.err > /tmp/ab.json || { tail -5 /tmp/ab.err; exit 1; }
+    python - "$V=$on" <<'PY'
+import json, sys
+d = json.load(open("/tmp/ab.json"))
+rb = d.get("reference_batch") or {}
+print(sys.argv[1], "ms/step", round(d["ms_per_step"], 2), "value", round(d["value"], 1), "B24 ms", round(rb.get("ms_per_step", 0.0), 2), flush=True)
+PY
+  done
+done

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Where the 256 x 256 tile GEMM spends its time: the forward launch of a few step shapes with parts of the kernel switched off
-(WM_GEMM_DBG bits: 1 no operand loads, 2 no MFMAs, 4 no epilogue).  Results are garbage by design; timing only."""
+(WM_GEMM_DBG bits: 1 no operand loads, 2 no MFMAs, 4 no epilogue).  Results are garbage by design; timing only.
+The switches are template instances that exist only in an ablation build of the library:
+    make -C image-in-speech-watermarking_amd/csrc clean && make -C image-in-speech-watermarking_amd/csrc ABLATE=1
+(the product build carries none of them; rebuild without ABLATE afterwards)."""
 import importlib, os, sys, math
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -4,7 +4,7 @@ An untrained extractor answers ~0.45 for every payload pixel, so BER sits at 0.5
 This module trains the HIP TrainStep (bf16, BASELINE config 3: full attack stack in the loop, extractor on the attacked
 spectrogram; step = audio_uformer_stft.py:421-540) on a synthetic stream until the payload is actually recovered, then
 hands the trained weights to the CPU oracle and compares decoded bits, BER (hidden/test_model.py:60-64) and tensors on
-held-out (tile, payload) pairs.  Used by bench.py (``ber_trained`` block), scripts/train_ber.py and tests/test_trained_ber_gpu.py.
+held-out (tile, payload) pairs.  Used by bench.py (``ber_trained`` block) and tests/test_trained_ber_gpu.py.
 
 Payloads: the reference trains on MNIST digits padded to 32 x 32 (audio_uformer_stft.py:210-220) — low-entropy images, not
 available offline.  The stand-in keeps that property: an 8 x 8 random bitmap shown as 4 x 4 pixel blocks (64 bits per

@@ -311,3 +311,13 @@ def test_reconstruct_audio_raw_sample_mode(wm, L):
         assert rel(a, b) <= 1e-4
     for i in (5, 6, 7):
         assert abs(g[i] - r[i]) <= 1e-4 * max(abs(r[i]), 1e-9), (i, g[i], r[i])
+    # a non-'0' audio_scale rescales the ENCODED clips in every data_mode (audio_test.py:559-571 sits in front of the branches);
+    # factor form f: audio_clip / f, range form lo-hi: back into [data_min, data_max].  No reference fixture: parity unpinned
+    gf = wm.evaluate.reconstruct_audio(data, msg.cuda(), Toy(dec), attack="amplitude_scaling-0.8", data_mode="audio",
+                                       model_name="modelA", audio_scale="10")
+    assert rel(gf[1], r[1] / 10.0) <= 1e-6
+    gr = wm.evaluate.reconstruct_audio(data, msg.cuda(), Toy(dec), attack="amplitude_scaling-0.8", data_mode="audio",
+                                       model_name="modelA", audio_scale="0.01-0.1", data_min=-2.0, data_max=3.0)
+    assert rel(gr[1], (r[1] - 0.01) / (0.1 - 0.01) * 5.0 - 2.0) <= 1e-5
+    with pytest.raises(ValueError):
+        wm.evaluate.reconstruct_audio(data, msg.cuda(), Toy(dec), data_mode="audio", model_name="modelA", audio_scale="0.01-0.1")

@@ -98,3 +98,24 @@ def test_model_with_and_without_fused_layernorm(wm, monkeypatch):
         assert rel(a, b) <= 2e-2, (name, rel(a, b))
     err = ((gf.double() - gu.double()).norm() / gu.double().norm()).item()
     assert err <= 5e-2, err
+
+
+def test_declined_fused_layernorm_falls_back_to_the_two_launches(wm):
+    """wm_gemm_ln_fusable(M, N, K, mode) says yes for shapes whose launchers then decline the DropPath scale (8 x 8 images:
+    64 rows per sample, not a multiple of the 256-row tile at N = 32).  linear_fwd must then produce the same pair of results
+    through the plain product + the LayerNorm kernel instead of raising."""
+    ops = wm.ops
+    B, hw, C, K = 8, 8, 32, 128
+    M = B * hw * hw
+    assert ops.ln_fusable(M, C, K, 1)
+    a, w = rnd("fa", (M, K)), rnd("fw", (C, K), 1.0 / math.sqrt(K))
+    bias, res = rnd("fb", (C,), 1.0, torch.float32), rnd("fr", (M, C), 1.0, torch.float32)
+    rs = torch.rand(B, device="cuda") + 0.5
+    gamma, beta = 1 + 0.1 * rnd("fg", (C,), 1.0, torch.float32), 0.1 * rnd("ft", (C,), 1.0, torch.float32)
+    out, y = torch.empty(M, C, device="cuda"), torch.empty(M, C, device="cuda", dtype=BF)
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.linear_fwd(a, w, bias, out, 1, res=res, rowscale=rs, rows_per_scale=hw * hw, ln=(gamma, beta, None, y, mean, rstd, hw, 0))
+    ref = (a.double() @ w.double().t() + bias.double()) * rs.double().repeat_interleave(hw * hw)[:, None] + res.double()
+    mu, var = ref.mean(1), ref.var(1, unbiased=False)
+    yref = (ref - mu[:, None]) / torch.sqrt(var[:, None] + 1e-5) * gamma.double() + beta.double()
+    assert rel(out, ref) <= 2e-4 and rel(y, yref) <= 4e-3 and rel(rstd, 1 / torch.sqrt(var + 1e-5)) <= 2e-4

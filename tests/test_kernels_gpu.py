@@ -148,6 +148,34 @@ def test_layernorm_fwd_bwd(wm, C):
 
 
 # ----------------------------------------------------------------------------- window attention
+def test_layernorm_bwd_scaled_bf16_copy(wm):
+    """dx_bf16 = bf16(dx * copy_scale[sample]): the gradient copy the next dX / dW products read already carries the DropPath
+    factor of their branch (model.py:1016-1017), so a sample that dropped the branch gets an all-zero copy while dx itself stays."""
+    ops = wm.ops
+    B, hw, C = 3, 8, 64
+    rows, N = B * hw * hw, hw * hw
+    x, gamma, beta = synth_array("cs_x", (rows, C)), 1 + 0.1 * synth_array("cs_g", (C,)), 0.1 * synth_array("cs_b", (C,))
+    dy, dres = synth_array("cs_dy", (rows, C)), synth_array("cs_dr", (rows, C))
+    xg = x.clone().requires_grad_()
+    (F.layer_norm(xg, (C,), gamma, beta) * dy).sum().backward()
+    want = xg.grad + dres
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    y = torch.empty(rows, C, device="cuda")
+    ops.layernorm_fwd(dev(x), dev(gamma), dev(beta), None, y, mean, rstd, hw, 0)
+    scale = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.7])
+    dx, dxh = torch.empty(rows, C, device="cuda"), torch.empty(rows, C, device="cuda", dtype=torch.bfloat16)
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    ops.layernorm_bwd(dev(dy), dev(x), dev(gamma), mean, rstd, dev(dres), dx, dg, db, None, hw, 0, dx_bf16=dxh,
+                      copy_scale=dev(scale), rows_per_scale=N)
+    assert_close(dx, want, 1e-4, "ln bwd dx")
+    ref_copy = (want * scale.repeat_interleave(N)[:, None]).to(torch.bfloat16).float()
+    assert_close(dxh.float(), ref_copy, 8e-3, "ln bwd scaled bf16 copy")
+    assert torch.count_nonzero(dxh[:N]) == 0 and torch.count_nonzero(dxh[N:]) > 0
+    # without a scale the copy is plain bf16(dx)
+    ops.layernorm_bwd(dev(dy), dev(x), dev(gamma), mean, rstd, dev(dres), dx, dg, db, None, hw, 0, dx_bf16=dxh)
+    assert_close(dxh.float(), want.to(torch.bfloat16).float(), 8e-3, "ln bwd bf16 copy")
+
+
 def ref_winattn(qkv, table, B, hw, C, shift):
     """Reference restated with torch ops on natural-order tokens (model.py:523-551, 954-1013)."""
     heads = C // 32

@@ -271,6 +271,55 @@ def test_resume_from_reference_format_checkpoint(wm, tmp_path):
 # ------------------------------------------------------------------------------------------------------------------
 # round 2: the benched mode (bf16) and the benched configurations (3 and 5) against the oracle
 # ------------------------------------------------------------------------------------------------------------------
+def test_reference_lr_schedule_drives_fused_adamw_under_graph_replay(wm):
+    """the reference trainer's schedule (audio_uformer_stft.py:347-356: CosineAnnealingLR behind a
+    GradualWarmupScheduler, stepped once per epoch, :545) on FusedAdamW while TrainStep REPLAYS its captured graph: the learning
+    rate lives in device memory, so a replay must pick each epoch's value up.  A stock torch.optim.AdamW under the same two
+    schedulers is fed the gradients the HIP step produced; the parameter arenas must agree after every step of five epochs."""
+    import warnings
+    tr = importlib.import_module("image-in-speech-watermarking_amd.train")
+    m = wm.UformerAudio(modulator=True, drop_path_rate=0.0, compute_mode="bf16")
+    load_synth(m)
+    m = m.cuda().train()
+    n = m.optimized_numel
+    hyper = dict(lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)          # audio_uformer_stft.py:252-255, options.py
+    opt = wm.FusedAdamW(m, **hyper)
+    shadow = torch.nn.Parameter(m._flat[:n].detach().clone())
+    ref = torch.optim.AdamW([shadow], **hyper)
+    nepoch, warm, per_epoch = 5, 2, 2
+
+    def schedule(o):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            cosine = torch.optim.lr_scheduler.CosineAnnealingLR(o, nepoch - warm, eta_min=1e-6)
+            sch = tr.GradualWarmupScheduler(o, multiplier=1, total_epoch=warm, after_scheduler=cosine)
+            sch.step()
+        return sch
+    s_hip, s_ref = schedule(opt), schedule(ref)
+    st = wm.TrainStep(m, opt, 1, use_graph=True)
+    x, msg = synth_tile(1, "lr_x").cuda(), synth_bits("lr_msg", (1, 1, 32, 32)).cuda()
+    lrs = []
+    for epoch in range(nepoch):
+        assert opt.param_groups[0]["lr"] == pytest.approx(ref.param_groups[0]["lr"], rel=1e-12)
+        lrs.append(opt.param_groups[0]["lr"])
+        for _ in range(per_epoch):
+            before = m._flat[:n].detach().clone()
+            st.step(x, msg)                                         # call 1: eager warm-up pass + capture; afterwards graph replays
+            torch.cuda.synchronize()
+            shadow.grad = m._flat_grad[:n].detach().clone()
+            ref.step()
+            moved = (m._flat[:n] - before).abs().mean().item()
+            err = (m._flat[:n] - shadow.detach()).abs().max().item()
+            assert moved > 0.2 * lrs[-1] and err <= 2e-6, (epoch, lrs[-1], moved, err)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            s_hip.step()
+            s_ref.step()
+    assert st._graph is not None                                    # the steps above were replays of ONE captured graph
+    assert lrs[0] == pytest.approx(1e-4) and lrs[1] == pytest.approx(2e-4) and len(set(lrs)) >= 4 and lrs[-1] < lrs[2]
+    assert float(opt.lr_t.item()) == pytest.approx(lrs[-1], rel=1e-6)
+
+
 def _record(name, payload):
     """Measured deviations go to gpurun_out/ (merged back from the GPU box; the judged copies live under profiles/)."""
     import json
@@ -312,6 +361,93 @@ def test_bf16_train_step_gradients_against_fp32_mode(wm):
     assert max(rec["loss_terms_rel"]) <= 1e-2, rec
     for name, e in rec["buckets"].items():
         assert e["norm_rel_err"] <= 4e-2 and e["cosine"] >= 0.999, (name, e)
+
+
+def test_bf16_droppath_backward_against_fp32_mode(wm):
+    """the bf16 DropPath backward (the benched default: bf16, drop_path_rate = 0.1) had no test.  In bf16 mode
+    layernorm_bwd writes the gradient copies pre-multiplied by the DropPath factor of the branch that reads them (dx1 * s1; dx * the
+    consumer block's s2) and the fc2 / proj dX and dW launches then take NO scale; a wrong or stale factor still trains.  Here both
+    modes run the reference-style loop with the SAME keep masks (some samples dropped in every block, some kept) and every gradient
+    bucket is compared norm-wise; the chains block -> down -> block and up -> block (where the copy is reset) are part of the net."""
+    B = 3
+    x, msg = synth_tile(B, "dp_x").cuda(), synth_bits("dp_msg", (B, 1, 32, 32)).cuda()
+    grads, terms = {}, {}
+    for mode in ("fp32", "bf16"):
+        m = wm.UformerAudio(modulator=True, drop_path_rate=0.1, compute_mode=mode)
+        load_synth(m)
+        m = m.cuda().train()
+        m._ensure_runtime(torch.device("cuda"))
+        rates = m._rates_host
+        scales = torch.ones(len(rates), B)
+        for s_, r in enumerate(rates):
+            if r > 0:
+                for b in range(B):
+                    scales[s_, b] = 0.0 if (5 * s_ + 3 * b) % 4 == 0 else 1.0 / (1.0 - r)
+        assert (scales == 0).any(dim=1).sum() >= 60 and (scales > 1).any(dim=1).sum() >= 100     # every stage drops and keeps
+        m.zero_grad(set_to_none=True)
+        out = m(x, msg, keep_scales=scales.cuda())
+        tot, tl = O.train_losses(out, x, msg)
+        tot.backward()
+        torch.cuda.synchronize()
+        grads[mode], terms[mode] = m._flat_grad.double().cpu(), torch.stack(tl).detach().double().cpu()
+        names = _bucket_names(m)
+    rec = {"loss_terms_rel": ((terms["bf16"] - terms["fp32"]).abs() / terms["fp32"].abs()).tolist(), "buckets": {}}
+    for name, lo, hi in names:
+        a, b = grads["bf16"][lo:hi], grads["fp32"][lo:hi]
+        rec["buckets"][name] = {"norm_rel_err": ((a - b).norm() / b.norm()).item(), "cosine": (a @ b / (a.norm() * b.norm())).item()}
+    _record("r04_parity_bf16_droppath_b3.json", rec)
+    # measured on MI355X (profiles/r04_parity_bf16_droppath_b3.json): encoder 1.4e-2, decoder 8e-3, extractor 6.2e-2 / cosine 0.9981
+    # (the extractor sees the bf16 deviation of the whole embedder through its INPUT; without DropPath it is 3.2e-2 / 0.9995, with
+    # the fused LeFF kernels switched off the same 6.0e-2 / 0.9982): bf16-vs-fp32 bounds cannot see a mis-placed factor in one
+    # block, the additivity test below can
+    assert max(rec["loss_terms_rel"]) <= 1e-2, rec
+    for name, e in rec["buckets"].items():
+        assert e["norm_rel_err"] <= 9e-2 and e["cosine"] >= 0.997, (name, e)
+
+
+def test_bf16_droppath_backward_is_additive_over_samples(wm):
+    """Sharp form of the test above.  With a loss that is LINEAR in the outputs (sum of outputs x fixed weights), the gradient of a
+    batch is the sum of its samples' gradients, and in bf16 mode every per-row operation rounds the same way alone or in a batch.
+    So a batched backward with per-sample DropPath factors must equal the three single-sample backwards with their own factor
+    columns up to fp32 summation order — a factor applied to the wrong sample, applied twice, or missing from one of the scaled
+    bf16 gradient copies (layernorm_bwd copy_scale, the consumer block's s2, the reset behind down / up-sampling) breaks it at
+    the 1e-1 level in that block's parameters."""
+    B = 3
+    x, msg = synth_tile(B, "da_x").cuda(), synth_bits("da_msg", (B, 1, 32, 32)).cuda()
+    m = wm.UformerAudio(modulator=True, drop_path_rate=0.1, compute_mode="bf16")
+    load_synth(m)
+    m = m.cuda().train()
+    m._ensure_runtime(torch.device("cuda"))
+    rates = m._rates_host
+    scales = torch.ones(len(rates), B)
+    for s_, r in enumerate(rates):
+        if r > 0:
+            for b in range(B):
+                scales[s_, b] = 0.0 if (5 * s_ + 3 * b) % 4 == 0 else 1.0 / (1.0 - r)
+    scales = scales.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(B, 2, 128, 128), (B, 2, 128, 128), (B, 1, 32, 32), (B, 1, 32, 32)]
+    G = [torch.randn(sh, device="cuda", generator=gen) for sh in shapes]
+
+    def grads(sl):
+        m.zero_grad(set_to_none=True)
+        out = m(x[sl], msg[sl], keep_scales=scales[:, sl].contiguous())
+        sum((o * g[sl]).sum() for o, g in zip(out, G)).backward()
+        torch.cuda.synchronize()
+        return m._flat_grad.double().cpu()
+    whole = grads(slice(0, B))
+    parts = sum(grads(slice(b, b + 1)) for b in range(B))
+    rec = {}
+    for name, lo, hi in _bucket_names(m):
+        a, b = whole[lo:hi], parts[lo:hi]
+        rec[name] = ((a - b).norm() / b.norm()).item()
+    # per owner (LeWin block / convolution): the largest relative deviation of any one block's parameters
+    worst = max((((whole[lo:hi] - parts[lo:hi]).norm() / parts[lo:hi].norm().clamp_min(1e-30)).item(), name)
+                for name, (lo, hi) in m._owner_range.items())
+    rec["worst_owner"] = worst
+    _record("r04_droppath_additivity_b3.json", rec)
+    assert all(v <= 2e-3 for k, v in rec.items() if k != "worst_owner"), rec
+    assert worst[0] <= 1e-2, worst
 
 
 def test_bf16_whole_model_b6_against_cpu_oracle(wm):
