@@ -161,7 +161,7 @@ __device__ __forceinline__ void fwd_stage(const FwdPre<C>& p, __bf16* Ws, float*
 }
 
 template <int C, bool SAVE>
-__global__ __launch_bounds__(256, 2) void leff_fwd_kernel(const __bf16* __restrict__ xn2, const float* __restrict__ x1,
+__global__ __launch_bounds__(256, C == 32 ? 4 : C == 64 ? 3 : 2) void leff_fwd_kernel(const __bf16* __restrict__ xn2, const float* __restrict__ x1,
                                                        const __bf16* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ wd, const float* __restrict__ bd,
                                                        const __bf16* __restrict__ w2, const float* __restrict__ b2,
@@ -176,9 +176,8 @@ __global__ __launch_bounds__(256, 2) void leff_fwd_kernel(const __bf16* __restri
   __bf16* const A2s = A1s + NPIX * HS;                                // gelu(h2): A operand of fc2
   float* const wl = reinterpret_cast<float*>(A2s + 64 * HS);          // depthwise weights [channel][tap], then the 64 biases
   float* const b1s = wl + 10 * TCH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid0 = threadIdx.x;
   const int nt = hw / TP, Ch = 4 * C;
-  const int c2 = tid & 31, py = tid >> 5;                             // depthwise stage: two channels of one tile row
   constexpr bool EARLY = C <= 64;                                     // when the next tile's image / this tile's residual are requested
   const int t0 = blockIdx.x * per, t1 = min(ntiles, t0 + per);       // consecutive tiles: neighbours share halo columns in L2
   if (t0 >= t1) return;
@@ -193,9 +192,17 @@ __global__ __launch_bounds__(256, 2) void leff_fwd_kernel(const __bf16* __restri
   FwdPre<C> pre;
   int b, ty, tx;
   tile_pos(t0, b, ty, tx);
-  if constexpr (EARLY) halo_load<C, __bf16>(xr, xn2, b, ty, tx, hw, tid);
-  fwd_prefetch<C>(pre, w1, b1, wd, bd, 0, tid);
+  if constexpr (EARLY) halo_load<C, __bf16>(xr, xn2, b, ty, tx, hw, tid0);
+  fwd_prefetch<C>(pre, w1, b1, wd, bd, 0, tid0);
   for (int t = t0; t < t1; ++t) {
+    // The per-thread indices are re-derived from an OPAQUE copy of the thread id in every tile: hipcc otherwise hoists every
+    // loop-invariant address component of the tile body (halo decode, epilogue row offsets, chunk indices) out of the
+    // persistent loop and keeps ~80 registers of them alive through all phases (184 -> 121 registers at C = 32: four
+    // workgroups per CU instead of two)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+    const int c2 = tid & 31, py = tid >> 5;                           // depthwise stage: two channels of one tile row
     tile_pos(t, b, ty, tx);
     if constexpr (!EARLY) halo_load<C, __bf16>(xr, xn2, b, ty, tx, hw, tid);
     halo_store<C>(Xs, xr, ty, tx, hw, tid);                           // (every reader of the previous tile's image is behind a barrier)
@@ -418,22 +425,27 @@ __global__ __launch_bounds__(256, 2) void leff_bwd_kernel(const DT* __restrict__
   float* const wl = reinterpret_cast<float*>(DH1s + 64 * HS);         // depthwise taps [channel][9]
   float* const RED = wl + 9 * TCH;                                    // per-wave sums of the slice's dw / db
   float* const ACC = RED + 4 * 10 * TCH;                              // [slice][tap | bias][channel] over the strip
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid0 = threadIdx.x;
   const int nt = hw / TP;
   const int strip = virtual_block(blockIdx.x, gridDim.x);
   const int b = strip / nt, ty = strip - b * nt;
   const int Ch = 4 * C;
-  const int c2 = tid & 31, py = tid >> 5;
   constexpr bool EARLY = C <= 64;                                     // the next tile's gradient image is requested a slice ahead
   const float sc = s2 ? s2[b] : 1.0f;
-  for (int i = tid; i < K::NCH * 10 * TCH; i += 256) ACC[i] = 0.f;
-  const int64_t strip0 = (((int64_t)b * hw + ty * TP + py) * hw) * Ch + 2 * c2;
+  for (int i = tid0; i < K::NCH * 10 * TCH; i += 256) ACC[i] = 0.f;
 
   u32x4 xr[K::NXL];
   BwdPre<C> pre;
-  if constexpr (EARLY) halo_load<C, DT>(xr, dy, b, ty, 0, hw, tid);
-  bwd_prefetch<C>(pre, h1, h2, wd, w2, b, ty, 0, hw, 0, strip0, tid);
+  if constexpr (EARLY) halo_load<C, DT>(xr, dy, b, ty, 0, hw, tid0);
+  bwd_prefetch<C>(pre, h1, h2, wd, w2, b, ty, 0, hw, 0, (((int64_t)b * hw + ty * TP + (tid0 >> 5)) * hw) * Ch + 2 * (tid0 & 31), tid0);
   for (int tx = 0; tx < nt; ++tx) {
+    // per-thread indices from an OPAQUE copy of the thread id in every tile (see the forward kernel: hipcc otherwise keeps every
+    // hoisted address component of the tile body alive across the whole strip)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+    const int c2 = tid & 31, py = tid >> 5;
+    const int64_t strip0 = (((int64_t)b * hw + ty * TP + py) * hw) * Ch + 2 * c2;
     if constexpr (!EARLY) halo_load<C, DT>(xr, dy, b, ty, tx, hw, tid);
     halo_store<C>(DYs, xr, ty, tx, hw, tid);
     f32x16 acc2[K::NTW];
@@ -605,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void leff_bwd_kernel(const DT* __restrict__
   }
   // the strip's dw [Ch][9] / db [Ch] as part[strip][Ch][10] (summed by the deferred reduction), or atomics without scratch;
   // ACC holds [slice][tap | bias][channel], the slices' taps lie [channel][9] in wl but were summed tap-major
-  for (int i = tid; i < Ch * 10; i += 256) {
+  for (int i = tid0; i < Ch * 10; i += 256) {
     const int ch = i / 10, k = i - ch * 10;
     const float v = ACC[(ch >> 6) * 10 * TCH + k * TCH + (ch & 63)];
     if (part) part[(int64_t)strip * Ch * 10 + i] = v;
@@ -617,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void leff_bwd_kernel(const DT* __restrict__
 bool ok(int B, int hw, int C) { return B > 0 && hw >= 8 && (hw & 7) == 0 && (C == 32 || C == 64 || C == 128); }
 
 // resident workgroups per CU (LDS and registers permitting): the persistent grid of the forward kernel
-template <int C> constexpr int fwd_wgs_per_cu() { return C == 32 ? 3 : 2; }
+template <int C> constexpr int fwd_wgs_per_cu() { return C == 32 ? 4 : C == 64 ? 3 : 2; }
 
 template <int C>
 int launch_fwd(const void* xn2, const float* x1, const void* w1, const float* b1, const float* wd, const float* bd, const void* w2,

@@ -155,9 +155,12 @@ def dwconv_bwd(h1, dh2, w, dh1, dw, db, B, hw, Ch, scratch=None, defer=None):
 
 
 def leff_fusable(hw, Cc):
-    """Do the fused LeFF kernels (csrc/leff_fused.hip) take this block?  (WM_NO_LEFF_FUSE=1: never — the A/B switch.)"""
+    """Does the model route this block's LeFF through the fused kernels (csrc/leff_fused.hip)?  They are parity-green at every
+    (hw, C <= 128) of the step but, measured on MI355X at B = 256 (scripts/leff_fused_bench.py, profiles/r04_leff_fused_bench_b256.txt),
+    the forward kernel is 8 % ahead of fc1 + depthwise + fc2 and the backward kernel 35 % behind its three launches (C = 128: one
+    workgroup per CU), 176.1 against 170.5 ms per step: the step keeps the separate launches unless WM_LEFF_FUSE=1."""
     import os
-    if os.environ.get("WM_NO_LEFF_FUSE", "0") == "1":
+    if os.environ.get("WM_LEFF_FUSE", "0") != "1":
         return False
     return bool(lib.wm_leff_fusable(hw, Cc))
 

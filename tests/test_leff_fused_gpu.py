@@ -49,7 +49,7 @@ SHAPES = [(2, 8, 32), (2, 16, 64), (3, 8, 128), (1, 128, 32), (1, 64, 64), (2, 3
 @pytest.mark.parametrize("B,hw,C", SHAPES)
 def test_leff_fused_fwd_bwd(wm, B, hw, C):
     ops = wm.ops
-    assert ops.leff_fusable(hw, C)
+    assert wm.lib.wm_leff_fusable(hw, C)
     bf = torch.bfloat16
     M, Ch = B * hw * hw, 4 * C
     D = torch.float64
@@ -120,8 +120,47 @@ def test_leff_fused_fwd_bwd(wm, B, hw, C):
 
 def test_leff_fused_rejects_what_it_does_not_take(wm):
     ops = wm.ops
-    assert not ops.leff_fusable(16, 256) and not ops.leff_fusable(12, 64) and not ops.leff_fusable(4, 32)
+    f = wm.lib.wm_leff_fusable
+    assert not f(16, 256) and not f(12, 64) and not f(4, 32) and f(8, 32) and f(64, 128)
     bf = torch.bfloat16
     x = torch.zeros(64, 256, device="cuda", dtype=bf)
     with pytest.raises(wm._lib.WmKernelError):
         ops.leff_fwd(x, x.float(), x, x.float(), x.float(), x.float(), x, x.float(), x.float(), 1, 8, 256)
+
+
+def test_model_with_and_without_fused_leff(wm, monkeypatch):
+    """Whole model, bf16, train mode with DropPath masks: the fused LeFF launches (WM_LEFF_FUSE=1: every block with C <= 128)
+    against the separate fc1 / depthwise / fc2 launches — outputs and the whole gradient arena."""
+    from synth import load_synth, synth_bits, synth_tile
+    B = 3
+    x, msg = synth_tile(B, "lf_x").cuda(), synth_bits("lf_m", (B, 1, 32, 32)).cuda()
+
+    def run(fused):
+        monkeypatch.setenv("WM_LEFF_FUSE", "1" if fused else "0")
+        net = wm.UformerAudio(modulator=True, drop_path_rate=0.1, compute_mode="bf16")
+        load_synth(net)
+        net = net.cuda().train()
+        net._ensure_runtime(torch.device("cuda"))
+        rates = net._rates_host
+        scales = torch.ones(len(rates), B)
+        for s_, r in enumerate(rates):
+            if r > 0:
+                for b in range(B):
+                    scales[s_, b] = 0.0 if (5 * s_ + 3 * b) % 4 == 0 else 1.0 / (1.0 - r)
+        net._flat_grad.zero_()
+        calls = []
+        orig = wm.ops.leff_fwd
+        monkeypatch.setattr(wm.ops, "leff_fwd", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        out = net(x, msg, keep_scales=scales.cuda())
+        (F.mse_loss(out[0], x) + F.mse_loss(out[2], msg) + F.mse_loss(out[3], msg) + out[1].square().mean()).backward()
+        torch.cuda.synchronize()
+        monkeypatch.undo()
+        return [o.detach().clone() for o in out], net._flat_grad.double().cpu(), len(calls)
+    of, gf, nf = run(True)
+    ou, gu, nu = run(False)
+    assert nf == 25 and nu == 0                                   # 2 trunks x (1 + 2 + 8) blocks + 2 + 1 decoder blocks with C <= 128
+    for a, b, name in zip(of, ou, ("stft_new", "noise", "wm_pred", "wm")):
+        assert rel(a, b) <= 2e-2, (name, rel(a, b))
+    err = ((gf - gu).norm() / gu.norm()).item()
+    cos = (gf @ gu / (gf.norm() * gu.norm())).item()
+    assert err <= 5e-2 and cos >= 0.999, (err, cos)
