@@ -15,6 +15,7 @@
 //             a workgroup walks.  Weights are staged as they lie and read with ds_read_b64_tr_b16 where the product wants
 //             them transposed.  ~30 C instead of 52 C.
 // fc1 / fc2 weight gradients stay on the TN GEMM (K = tokens): fc2's reads the saved h2 with GELU applied while staging.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "gelu_poly.h"
@@ -42,6 +43,12 @@ template <int C> struct Cfg {
   static constexpr int FWD_SMEM = (NPIX * XS + WS_EL + NPIX * HS + 64 * HS) * 2 + (10 * TCH + TCH) * 4;
   static constexpr int BWD_SMEM = (NPIX * XS + WS_EL + NPIX * HS + 64 * HS) * 2 + (9 * TCH + 4 * 10 * TCH + NCH * 10 * TCH) * 4;
 };
+
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)): every barrier of a slice would then wait until the h1 / h2 / dh1 rows stored in the phase before it
+// have been acknowledged by the L2 (1 - 2 us under load, five times per slice).  No phase reads global data another thread of
+// the workgroup wrote, so only LDS visibility matters; loads are waited for by the compiler where their registers are used.
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ int virtual_block(int id, int n) { return (n & 7) ? id : (id & 7) * (n >> 3) + (id >> 3); }
 
@@ -160,7 +167,7 @@ __device__ __forceinline__ void fwd_stage(const FwdPre<C>& p, __bf16* Ws, float*
   if (tid < TCH) b1s[tid] = p.bv;
 }
 
-template <int C, bool SAVE>
+template <int C, int SAVE, bool NTS>
 __global__ __launch_bounds__(256, C == 32 ? 4 : C == 64 ? 3 : 2) void leff_fwd_kernel(const __bf16* __restrict__ xn2, const float* __restrict__ x1,
                                                        const __bf16* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ wd, const float* __restrict__ bd,
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256, C == 32 ? 4 : C == 64 ? 3 : 2) void leff_fwd_k
       constexpr bool LAST = decltype(last_c)::value;
       const int hb = kc * TCH;
       fwd_stage<C>(pre, Ws, wl, b1s, tid);
-      __syncthreads();
+      wg_barrier();
       // W2 slice [C][64] into registers: lands while fc1 runs
       u32x4 w2r[C / 32];
 #pragma unroll
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256, C == 32 ? 4 : C == 64 ? 3 : 2) void leff_fwd_k
             }
         }
       }
-      __syncthreads();
+      wg_barrier();
       // the next slice's operands (slice 0 again behind the last one: the next tile's), the next tile's image and this tile's
       // residual rows are requested here and used a slice / an epilogue later
       fwd_prefetch<C>(pre, w1, b1, wd, bd, kc + 1 < K::NCH ? hb + TCH : 0, tid);
@@ -287,8 +294,11 @@ __global__ __launch_bounds__(256, C == 32 ? 4 : C == 64 ? 3 : 2) void leff_fwd_k
             const Pix p(pix, ty, tx, hw);
             __bf16* cell = A1s + pix * HS + part * 8;
             const u32x4 v = *reinterpret_cast<const u32x4*>(cell);
-            if (SAVE && p.centre)
-              stream_store(h1 + (((int64_t)b * hw + p.gy) * hw + p.gx) * Ch + hb + part * 8, make_uint4(v.x, v.y, v.z, v.w));
+            if ((SAVE & 1) && p.centre) {
+              __bf16* dst = h1 + (((int64_t)b * hw + p.gy) * hw + p.gx) * Ch + hb + part * 8;
+              if (NTS) stream_store(dst, make_uint4(v.x, v.y, v.z, v.w));
+              else *reinterpret_cast<u32x4*>(dst) = v;
+            }
             u32x4 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(256, C == 32 ? 4 : C == 64 ? 3 : 2) void leff_fwd_k
           *reinterpret_cast<u32x4*>(Ws + n * HS + part * 8) = w2r[k];
         }
       }
-      __syncthreads();
+      wg_barrier();
       {                                                               // depthwise 3 x 3, second GELU
         f32x2 wr[9], br;
 #pragma unroll
@@ -326,13 +336,16 @@ __global__ __launch_bounds__(256, C == 32 ? 4 : C == 64 ? 3 : 2) void leff_fwd_k
           for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) o += wr[dy * 3 + dx] * col[(px + dx) % 3][dy];
-          if (SAVE) stream_store(h2 + row0 + (int64_t)px * Ch + hb, pack_bf2(o.x, o.y));
+          if (SAVE & 2) {
+            if (NTS) stream_store(h2 + row0 + (int64_t)px * Ch + hb, pack_bf2(o.x, o.y));
+            else *reinterpret_cast<uint32_t*>(h2 + row0 + (int64_t)px * Ch + hb) = pack_bf2(o.x, o.y);
+          }
           f32x2 av, gv;
           gelu_pair<__bf16>(o, av, gv);
           *reinterpret_cast<uint32_t*>(A2s + (py * TP + px) * HS + 2 * c2) = pack_bf2(av.x, av.y);
         }
       }
-      __syncthreads();
+      wg_barrier();
       (void)tile_prefetch;
 #pragma unroll
       for (int i = 0; i < K::NTW; ++i) {                              // fc2: x2[token][channel] += gelu(h2) . W2 slice^T
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(256, C == 32 ? 4 : C == 64 ? 3 : 2) void leff_fwd_k
                                                               row_frag<HS>(Ws, 32 * ct + r, ks, h), acc2[i], 0, 0, 0);
         }
       }
-      __syncthreads();
+      wg_barrier();
     };
     for (int kc = 0; kc < K::NCH - 1; ++kc) slice(kc, std::false_type{});
     slice(K::NCH - 1, std::true_type{});
@@ -475,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void leff_bwd_kernel(const DT* __restrict__
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         if (tid + 256 * k < 9 * TCH) wl[tid + 256 * k] = pre.wv[k];
-      __syncthreads();
+      wg_barrier();
       // W1 slice [64][C] into registers: lands while the first product runs
       constexpr int NL1 = TCH * K::CPR / 256;
       u32x4 w1r[NL1];
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void leff_bwd_kernel(const DT* __restrict__
             }
         }
       }
-      __syncthreads();
+      wg_barrier();
 #pragma unroll
       for (int k = 0; k < NL1; ++k) {                                 // W1 slice as it lies (the first product is done with Ws)
         const int idx = tid + 256 * k, row = idx / K::CPR, part_ = idx - row * K::CPR;
@@ -575,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void leff_bwd_kernel(const DT* __restrict__
           *reinterpret_cast<float2*>(dst + 9 * TCH) = make_float2(ab.x, ab.y);
         }
       }
-      __syncthreads();
+      wg_barrier();
 #pragma unroll
       for (int i = 0; i < K::NTW; ++i) {                              // dxn2[channel][token] += (W1 slice)^T dh1^T
         const int tile = wave + 4 * i;
@@ -589,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void leff_bwd_kernel(const DT* __restrict__
       }
       for (int i = tid; i < 10 * TCH; i += 256)
         ACC[kc * 10 * TCH + i] += (RED[i] + RED[10 * TCH + i]) + (RED[2 * 10 * TCH + i] + RED[3 * 10 * TCH + i]);
-      __syncthreads();
+      wg_barrier();
     };
     for (int kc = 0; kc < K::NCH - 1; ++kc) slice(kc, std::false_type{});
     slice(K::NCH - 1, std::true_type{});
@@ -605,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void leff_bwd_kernel(const DT* __restrict__
               pack4(acc2[i][4 * g], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
       }
     }
-    __syncthreads();
+    wg_barrier();
 #pragma unroll
     for (int k = 0; k < C / 32; ++k) {
       const int idx = tid + 256 * k, tok = idx / K::CPR, part_ = idx - tok * K::CPR;
@@ -613,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void leff_bwd_kernel(const DT* __restrict__
       const u32x4 v = *reinterpret_cast<const u32x4*>(DYs + tok * K::XS + part_ * 8);
       stream_store(dxn2 + grow * C + part_ * 8, make_uint4(v.x, v.y, v.z, v.w));
     }
-    __syncthreads();
+    wg_barrier();
   }
   // the strip's dw [Ch][9] / db [Ch] as part[strip][Ch][10] (summed by the deferred reduction), or atomics without scratch;
   // ACC holds [slice][tap | bias][channel], the slices' taps lie [channel][9] in wl but were summed tap-major
@@ -631,15 +644,14 @@ bool ok(int B, int hw, int C) { return B > 0 && hw >= 8 && (hw & 7) == 0 && (C =
 // resident workgroups per CU (LDS and registers permitting): the persistent grid of the forward kernel
 template <int C> constexpr int fwd_wgs_per_cu() { return C == 32 ? 4 : C == 64 ? 3 : 2; }
 
-template <int C>
-int launch_fwd(const void* xn2, const float* x1, const void* w1, const float* b1, const float* wd, const float* bd, const void* w2,
-               const float* b2, const float* s2, float* x2, void* h1, void* h2, int B, int hw, hipStream_t st) {
+template <int C, int SAVE, bool NTS>
+int launch_fwd_v(const void* xn2, const float* x1, const void* w1, const float* b1, const float* wd, const float* bd, const void* w2,
+                 const float* b2, const float* s2, float* x2, void* h1, void* h2, int B, int hw, hipStream_t st) {
   const int tiles = B * (hw / TP) * (hw / TP);
   constexpr int SM = Cfg<C>::FWD_SMEM;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leff_fwd_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leff_fwd_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leff_fwd_kernel<C, SAVE, NTS>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
     attr = true;
   }
   // a contiguous range of tiles per workgroup; ranges of at most 8 tiles so that small launches still cover the chip
@@ -647,16 +659,24 @@ int launch_fwd(const void* xn2, const float* x1, const void* w1, const float* b1
   int per = (tiles + slots - 1) / slots;
   per = per < 1 ? 1 : (per > 8 ? 8 : per);
   const int grid = (tiles + per - 1) / per;
-  if (h1 && h2)
-    hipLaunchKernelGGL((leff_fwd_kernel<C, true>), dim3(grid), dim3(256), SM, st, static_cast<const __bf16*>(xn2), x1,
-                       static_cast<const __bf16*>(w1), b1, wd, bd, static_cast<const __bf16*>(w2), b2, s2, x2,
-                       static_cast<__bf16*>(h1), static_cast<__bf16*>(h2), B, hw, tiles, per);
-  else
-    hipLaunchKernelGGL((leff_fwd_kernel<C, false>), dim3(grid), dim3(256), SM, st, static_cast<const __bf16*>(xn2), x1,
-                       static_cast<const __bf16*>(w1), b1, wd, bd, static_cast<const __bf16*>(w2), b2, s2, x2,
-                       static_cast<__bf16*>(nullptr), static_cast<__bf16*>(nullptr), B, hw, tiles, per);
+  hipLaunchKernelGGL((leff_fwd_kernel<C, SAVE, NTS>), dim3(grid), dim3(256), SM, st, static_cast<const __bf16*>(xn2), x1,
+                     static_cast<const __bf16*>(w1), b1, wd, bd, static_cast<const __bf16*>(w2), b2, s2, x2,
+                     static_cast<__bf16*>(h1), static_cast<__bf16*>(h2), B, hw, tiles, per);
   WM_CHECK_LAUNCH();
   return WM_OK;
+}
+template <int C>
+int launch_fwd(const void* xn2, const float* x1, const void* w1, const float* b1, const float* wd, const float* bd, const void* w2,
+               const float* b2, const float* s2, float* x2, void* h1, void* h2, int B, int hw, hipStream_t st) {
+  static const bool plain = getenv("WM_LEFF_PLAIN_STORES") != nullptr;       // (experiment switch)
+  const int save = (h1 ? 1 : 0) | (h2 ? 2 : 0);
+#define WM_LF(S, N) return launch_fwd_v<C, S, N>(xn2, x1, w1, b1, wd, bd, w2, b2, s2, x2, h1, h2, B, hw, st)
+  if (plain) { if (save == 3) WM_LF(3, false); if (save == 2) WM_LF(2, false); if (save == 1) WM_LF(1, false); }
+  if (save == 3) WM_LF(3, true);
+  if (save == 2) WM_LF(2, true);
+  if (save == 1) WM_LF(1, true);
+  WM_LF(0, true);
+#undef WM_LF
 }
 
 template <int C>
@@ -689,7 +709,7 @@ extern "C" int32_t wm_leff_fusable(int32_t hw, int32_t C) { return ok(1, hw, C) 
 extern "C" int wm_leff_fwd(const void* xn2, const float* x1, const void* w1, const float* b1, const float* wd, const float* bd,
                            const void* w2, const float* b2, const float* rowscale, float* x2, void* h1, void* h2, int32_t B,
                            int32_t hw, int32_t C, void* stream) {
-  if (!xn2 || !x1 || !w1 || !b1 || !wd || !bd || !w2 || !b2 || !x2 || (!h1) != (!h2) || !ok(B, hw, C)) return WM_EINVAL;
+  if (!xn2 || !x1 || !w1 || !b1 || !wd || !bd || !w2 || !b2 || !x2 || !ok(B, hw, C)) return WM_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (C == 32) return launch_fwd<32>(xn2, x1, w1, b1, wd, bd, w2, b2, rowscale, x2, h1, h2, B, hw, st);
   if (C == 64) return launch_fwd<64>(xn2, x1, w1, b1, wd, bd, w2, b2, rowscale, x2, h1, h2, B, hw, st);

@@ -471,20 +471,35 @@ class UformerAudio(nn.Module):
         M, N = x.shape[0], hw * hw
         H, W = self._H, self._W
         half = self.compute_mode == "bf16"
-        if ln1 is None:
+        attn_fused = half and ops.attn_half_fusable(hw, C)
+        if attn_fused:
+            # C <= 128: norm1 (+ modulator) -> q | k | v -> window attention -> projection (+ DropPath, + residual) -> norm2 as ONE
+            # window-local launch (csrc/attn_fused.hip); xn1 / qkv / o are written for the backward launches
+            xn1, qkv, o = H(dev, M, C), H(dev, M, 3 * C), H(dev, M, C)
+            mean1, rstd1, mean2, rstd2, lse = _E(dev, M), _E(dev, M), _E(dev, M), _E(dev, M), _E(dev, M, C // 32)
+            x1, xn2 = _E(dev, M, C), H(dev, M, C)
+            ops.attn_half_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], P[pre + "modulator.weight"] if mod else None,
+                              W(pre + "attn.qkv.w"), P[pre + "attn.qkv.b"], P[pre + "attn.relative_position_bias_table"],
+                              W(pre + "attn.proj.weight"), P[pre + "attn.proj.bias"], P[pre + "norm2.weight"], P[pre + "norm2.bias"],
+                              x1, xn2, mean1, rstd1, mean2, rstd2, lse, B, hw, C, shift, rowscale=s1, xn1=xn1, qkv=qkv, o=o)
+            next_ln = None                                         # the next block of this stage normalises its own input
+        elif ln1 is None:
             xn1, mean1, rstd1 = H(dev, M, C), _E(dev, M), _E(dev, M)
             ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], P[pre + "modulator.weight"] if mod else None,
                               xn1, mean1, rstd1, hw, shift)
         else:
             xn1, mean1, rstd1 = ln1
-        qkv = H(dev, M, 3 * C)
-        ops.linear_fwd(xn1, W(pre + "attn.qkv.w"), P[pre + "attn.qkv.b"], qkv, mode)
-        o = H(dev, M, C)
-        lse = _E(dev, M, C // 32) if mode else None                # the MFMA kernels (bf16 and split) keep the row log-sum-exp
-        ops.winattn_fwd(qkv, P[pre + "attn.relative_position_bias_table"], o, B, hw, C, shift, mode, lse=lse)
-        x1 = _E(dev, M, C)
-        xn2, mean2, rstd2 = H(dev, M, C), _E(dev, M), _E(dev, M)
-        if half and ops.ln_fusable(M, C, C, mode):
+        if not attn_fused:
+            qkv = H(dev, M, 3 * C)
+            ops.linear_fwd(xn1, W(pre + "attn.qkv.w"), P[pre + "attn.qkv.b"], qkv, mode)
+            o = H(dev, M, C)
+            lse = _E(dev, M, C // 32) if mode else None            # the MFMA kernels (bf16 and split) keep the row log-sum-exp
+            ops.winattn_fwd(qkv, P[pre + "attn.relative_position_bias_table"], o, B, hw, C, shift, mode, lse=lse)
+            x1 = _E(dev, M, C)
+            xn2, mean2, rstd2 = H(dev, M, C), _E(dev, M), _E(dev, M)
+        if attn_fused:
+            pass
+        elif half and ops.ln_fusable(M, C, C, mode):
             ops.linear_fwd(o, W(pre + "attn.proj.weight"), P[pre + "attn.proj.bias"], x1, mode, res=x, rowscale=s1, rows_per_scale=N,
                            ln=(P[pre + "norm2.weight"], P[pre + "norm2.bias"], None, xn2, mean2, rstd2, hw, 0))
         else:

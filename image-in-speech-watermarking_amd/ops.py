@@ -154,6 +154,27 @@ def dwconv_bwd(h1, dh2, w, dh1, dw, db, B, hw, Ch, scratch=None, defer=None):
                             _stream()), "wm_dwconv_bwd")
 
 
+def attn_half_fusable(hw, Cc):
+    """Does the model route this block's attention half through the fused window-local kernel (csrc/attn_fused.hip)?
+    (WM_NO_ATTN_FUSE=1: never — the A/B switch of the benchmarks.)"""
+    import os
+    if os.environ.get("WM_NO_ATTN_FUSE", "0") == "1":
+        return False
+    return bool(lib.wm_attn_half_fusable(hw, Cc))
+
+
+def attn_half_fwd(x, g1, b1, mod, wqkv, bqkv, table, wproj, bproj, g2, b2, x1, xn2, mean1, rstd1, mean2, rstd2, lse, B, hw, Cc, shift,
+                  rowscale=None, xn1=None, qkv=None, o=None):
+    """x1 = x + rowscale * proj(window_attention(norm1(x) (+ mod))), xn2 = norm2(x1) in ONE launch (csrc/attn_fused.hip).
+    xn1 / qkv / o (bf16, all or none): also written, for the un-fused backward launches."""
+    for t in (wqkv, wproj, xn2, xn1, qkv, o):
+        if t is not None and t.dtype != torch.bfloat16:
+            raise ValueError("attn_half_fwd: wqkv, wproj, xn2, xn1, qkv, o are bfloat16 tensors (bf16 mode only)")
+    check(lib.wm_attn_half_fwd(ptr(x), ptr(g1), ptr(b1), ptr(mod), ptr(wqkv), ptr(bqkv), ptr(table), ptr(wproj), ptr(bproj),
+                               ptr(rowscale), ptr(g2), ptr(b2), ptr(x1), ptr(xn2), ptr(mean1), ptr(rstd1), ptr(mean2), ptr(rstd2),
+                               ptr(lse), ptr(xn1), ptr(qkv), ptr(o), B, hw, Cc, shift, _stream()), "wm_attn_half_fwd")
+
+
 def leff_fusable(hw, Cc):
     """Does the model route this block's LeFF through the fused kernels (csrc/leff_fused.hip)?  They are parity-green at every
     (hw, C <= 128) of the step but, measured on MI355X at B = 256 (scripts/leff_fused_bench.py, profiles/r04_leff_fused_bench_b256.txt),

@@ -124,6 +124,21 @@ int64_t wm_dwconv_bwd_scratch_floats(int32_t B, int32_t hw, int32_t Ch);
 int wm_dwconv_bwd(const void* h1, const void* dh2, const float* w, void* dh1, float* dw, float* db, float* scratch,
                   WmReduceJob* defer /* 2 entries or NULL */, int32_t io_bf16, int32_t B, int32_t hw, int32_t Ch, void* stream);
 
+/* ---- The attention half of a LeWin block as one window-local kernel (blocks with C in {32, 64, 128}, bf16 operands) —
+ * LeWinTransformerBlock.forward, model.py:982-1016 (norm1, roll / window partition, modulator :996-997, WindowAttention :523-551,
+ * window reverse / roll back, x + drop_path(...)) and the norm2 of :1017.  Replaces, for those blocks, wm_layernorm_fwd +
+ * the q | k | v product + wm_winattn_fwd + the projection product (+ its fused norm2).
+ *   x1 = x + rowscale[sample] * (attention(norm1(x) (+ modulator)) Wproj^T + bproj),  xn2 = norm2(x1) (bf16),
+ *   mean1 / rstd1 / mean2 / rstd2 [tokens]: the row statistics of the two LayerNorms, lse [tokens, heads]: softmax log-sum-exp.
+ *   wqkv [3C, C] (q rows, then k, then v) / wproj [C, C]: bf16 copies of the parameters; bias_table [225, heads].
+ *   xn1 [tokens, C], qkv [tokens, 3C], o [tokens, C] (bf16; all three or none): what the un-fused backward launches read.  */
+int32_t wm_attn_half_fusable(int32_t hw, int32_t C);
+int wm_attn_half_fwd(const float* x, const float* gamma1, const float* beta1, const float* modulator /* [64, C] or NULL */,
+                     const void* wqkv_bf16, const float* bqkv, const float* bias_table, const void* wproj_bf16, const float* bproj,
+                     const float* rowscale /* [B] or NULL */, const float* gamma2, const float* beta2, float* x1, void* xn2,
+                     float* mean1, float* rstd1, float* mean2, float* rstd2, float* lse, void* xn1, void* qkv, void* o,
+                     int32_t B, int32_t hw, int32_t C, int32_t shift, void* stream);
+
 /* ---- LeFF as two fused kernels (blocks with C in {32, 64, 128}, bf16 storage) — model.py:695-714 + the residual / DropPath add of
  * :1016-1017.  Replaces, for those blocks, linear1 + wm_dwconv_fwd + linear2 (forward) and linear2's input gradient +
  * wm_dwconv_bwd + linear1's input gradient (backward); the two weight-gradient products stay on wm_gemm (fc2's reads the saved

@@ -31,6 +31,15 @@ def block_payloads(n, gen, device="cpu"):
     return bits.repeat_interleave(4, 2).repeat_interleave(4, 3).contiguous().to(device)
 
 
+def binary_payloads(n, gen, device="cpu"):
+    """[n,1,32,32] float payloads of the configs' own kind: BinaryWM, 32 x 32 independent random bits = 1024 bits per payload
+    (uformerWM/audio_uformer_stft.py:222-244: ``torch.randint(0, 2, (32, 32))``), fresh ones for every sample."""
+    return torch.randint(0, 2, (n, 1, 32, 32), generator=gen).float().to(device)
+
+
+PAYLOADS = {"block": block_payloads, "binary": binary_payloads}
+
+
 def tile_pool(wm, n, dev, tag="ber", scale=1.0):
     """n synthetic speech-like STFT tiles through the device data-prep path; `scale` as the reference's
     audio_scale factor (audio_test.py:44-55 scales the tiles into a unit-ish range before training)."""
@@ -63,9 +72,12 @@ def evaluate(wm, net, x, msg):
     return out
 
 
-def train(wm, steps, batch=32, mode="bf16", lr=2e-4, eval_every=50, pool=256, held_out=16, seed=0, log=None, scale=0.05):
+def train(wm, steps, batch=32, mode="bf16", lr=2e-4, eval_every=50, pool=256, held_out=16, seed=0, log=None, scale=0.05,
+          payload="block", eval_at=None):
     """Fresh UformerAudio (its own default initialisation, torch seed `seed`) trained for `steps` captured steps of config 3.
-    Returns (net, curve, held-out x, held-out payloads)."""
+    payload: 'block' (64-bit stand-in for the MNIST digits) or 'binary' (BinaryWM: 1024 random bits, the configs' payload);
+    eval_at: explicit list of evaluation steps (else every `eval_every`).  Returns (net, curve, held-out x, held-out payloads)."""
+    make = PAYLOADS[payload]
     dev = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(seed)
     net = wm.UformerAudio(img_size=128, embed_dim=32, win_size=8, token_projection="linear", token_mlp="leff",
@@ -76,10 +88,10 @@ def train(wm, steps, batch=32, mode="bf16", lr=2e-4, eval_every=50, pool=256, he
     step = wm.TrainStep(net, opt, batch, attack=wm.AttackConfig(**FULL_STACK), extract_from="attacked")
     gen = torch.Generator().manual_seed(seed + 1)
     tiles = tile_pool(wm, pool + held_out, dev, scale=scale)
-    xh, mh = tiles[pool:].contiguous(), block_payloads(held_out, torch.Generator().manual_seed(seed + 2), dev)
+    xh, mh = tiles[pool:].contiguous(), make(held_out, torch.Generator().manual_seed(seed + 2), dev)
     curve = []
     for it in range(steps + 1):
-        if it % eval_every == 0 or it == steps:
+        if (it in eval_at if eval_at is not None else it % eval_every == 0) or it == steps:
             e = evaluate(wm, net, xh, mh)
             e["step"] = it
             e["loss_terms"] = [round(v, 5) for v in step.losses.cpu().tolist()[:5]] if it else None
@@ -89,7 +101,7 @@ def train(wm, steps, batch=32, mode="bf16", lr=2e-4, eval_every=50, pool=256, he
         if it == steps:
             break
         idx = torch.randint(0, pool, (batch,), generator=gen)
-        step.step(tiles[idx.to(dev)], block_payloads(batch, gen, dev))
+        step.step(tiles[idx.to(dev)], make(batch, gen, dev))
     torch.cuda.synchronize()
     step.release()
     return net, curve, xh, mh
@@ -158,11 +170,12 @@ def main():
     ap.add_argument("--mode", default="bf16")
     ap.add_argument("--scale", type=float, default=0.05)
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--payload", default="block", choices=sorted(PAYLOADS))
     a = ap.parse_args()
     wm = importlib.import_module("image-in-speech-watermarking_amd")
-    net, curve, xh, mh = train(wm, a.steps, a.batch, a.mode, a.lr, a.eval_every, scale=a.scale,
+    net, curve, xh, mh = train(wm, a.steps, a.batch, a.mode, a.lr, a.eval_every, scale=a.scale, payload=a.payload,
                                log=lambda e: print(json.dumps(e), file=sys.stderr, flush=True))
-    res = {"steps": a.steps, "batch": a.batch, "lr": a.lr, "mode": a.mode, "tile_scale": a.scale, "curve": curve}
+    res = {"steps": a.steps, "batch": a.batch, "lr": a.lr, "mode": a.mode, "tile_scale": a.scale, "payload": a.payload, "curve": curve}
     if not a.no_oracle:
         res["oracle_parity"] = oracle_parity(wm, net, xh, mh, 8)
     print(json.dumps(res))

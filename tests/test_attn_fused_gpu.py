@@ -1,0 +1,135 @@
+"""The fused attention half (csrc/attn_fused.hip) against torch float64 on the same bf16-rounded weights, and against the un-fused
+launch chain it replaces.
+
+Reference semantics: LeWinTransformerBlock.forward (uformerWM/model.py:982-1017): norm1, cyclic shift + window partition,
+modulator (:996-997), WindowAttention (:523-551) with the shift mask (:954-972), window reverse + shift back, x + drop_path(.),
+and norm2 of the result.  The kernel keeps xn1, q | k | v, the softmax probabilities and the attention output as bf16 (as the
+un-fused bf16 path does), so x1 is held to a few bf16 ulps of the BRANCH's scale and xn2 to bf16 rounding.
+"""
+import importlib
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import uformer_wm as O
+from synth import synth_array
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def wm():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return importlib.import_module("image-in-speech-watermarking_amd")
+
+
+def bfr(t):
+    return t.to(BF).to(t.dtype)
+
+
+def dev(t, dtype=torch.float32):
+    return t.to(dtype).contiguous().cuda()
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def window_pos(rows, hw, shift):
+    t = torch.arange(rows) % (hw * hw)
+    yy, xx = t // hw, t % hw
+    i, j = (yy - shift + hw) % hw, (xx - shift + hw) % hw
+    return (i & 7) * 8 + (j & 7)
+
+
+def ref_winattn(qkv, table, B, hw, C, shift):
+    heads = C // 32
+    t = qkv.view(B, hw, hw, 3 * C)
+    if shift:
+        t = torch.roll(t, (-shift, -shift), (1, 2))
+    t = t.view(B, hw // 8, 8, hw // 8, 8, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 64, 3, heads, 32)
+    q, k, v = (t[:, :, i].transpose(1, 2) for i in range(3))
+    s = (q * 32 ** -0.5) @ k.transpose(-1, -2)
+    s = s + table[O.rel_pos_index(8).reshape(-1)].view(64, 64, heads).permute(2, 0, 1)
+    if shift:
+        m = O.shift_attn_mask(hw, 8, shift).to(s.dtype)
+        nw = m.shape[0]
+        s = (s.view(B, nw, heads, 64, 64) + m[None, :, None]).view(-1, heads, 64, 64)
+    lse = torch.logsumexp(s, -1)                                        # [windows, heads, 64]
+    o = (s.softmax(-1) @ v).transpose(1, 2).reshape(-1, 64, C)
+    o = o.view(B, hw // 8, hw // 8, 8, 8, C).permute(0, 1, 3, 2, 4, 5).reshape(B, hw, hw, C)
+    lse = lse.permute(0, 2, 1).reshape(B, hw // 8, hw // 8, 8, 8, heads).permute(0, 1, 3, 2, 4, 5).reshape(B, hw, hw, heads)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+        lse = torch.roll(lse, (shift, shift), (1, 2))
+    return o.reshape(B * hw * hw, C), lse.reshape(B * hw * hw, heads)
+
+
+SHAPES = [(2, 8, 32, 0, False), (2, 16, 64, 4, True), (1, 16, 128, 4, False), (1, 64, 32, 4, True), (1, 32, 64, 0, False),
+          (3, 8, 128, 0, True), (1, 32, 128, 4, True)]
+
+
+@pytest.mark.parametrize("B,hw,C,shift,use_mod", SHAPES)
+def test_attn_half_fwd(wm, B, hw, C, shift, use_mod):
+    ops = wm.ops
+    assert wm.lib.wm_attn_half_fusable(hw, C)
+    D = torch.float64
+    M, heads = B * hw * hw, C // 32
+    tag = f"{B}_{hw}_{C}_{shift}"
+    x = synth_array("ax" + tag, (M, C)).to(D)
+    g1, b1 = (1 + 0.1 * synth_array("ag1" + tag, (C,))).to(D), (0.1 * synth_array("ab1" + tag, (C,))).to(D)
+    g2, b2 = (1 + 0.1 * synth_array("ag2" + tag, (C,))).to(D), (0.1 * synth_array("ab2" + tag, (C,))).to(D)
+    mod = (0.5 * synth_array("am" + tag, (64, C))).to(D) if use_mod else None
+    wqkv = bfr(synth_array("awq" + tag, (3 * C, C), 1.0 / math.sqrt(C))).to(D)
+    bqkv = (0.2 * synth_array("abq" + tag, (3 * C,))).to(D)
+    wproj = bfr(synth_array("awp" + tag, (C, C), 1.0 / math.sqrt(C))).to(D)
+    bproj = (0.2 * synth_array("abp" + tag, (C,))).to(D)
+    table = (0.5 * synth_array("at" + tag, (225, heads))).to(D)
+    s1 = (torch.rand(B, generator=torch.Generator().manual_seed(3)) + 0.5).to(D)
+    srow = s1.repeat_interleave(hw * hw)[:, None]
+    # ---- float64 reference
+    xn1 = F.layer_norm(x, (C,), g1, b1)
+    if use_mod:
+        xn1 = xn1 + mod[window_pos(M, hw, shift)]
+    qkv = xn1 @ wqkv.t() + bqkv
+    o, lse = ref_winattn(qkv, table, B, hw, C, shift)
+    branch = (o @ wproj.t() + bproj) * srow
+    x1 = x + branch
+    xn2 = F.layer_norm(x1, (C,), g2, b2)
+    # ---- kernel
+    f32 = lambda *s_: torch.empty(*s_, device="cuda")
+    h16 = lambda *s_: torch.empty(*s_, device="cuda", dtype=BF)
+    x1d, xn2d = f32(M, C), h16(M, C)
+    m1, r1, m2, r2, lsed = f32(M), f32(M), f32(M), f32(M), f32(M, heads)
+    xn1d, qkvd, od = h16(M, C), h16(M, 3 * C), h16(M, C)
+    args = (dev(x), dev(g1), dev(b1), dev(mod) if use_mod else None, dev(wqkv, BF), dev(bqkv), dev(table), dev(wproj, BF),
+            dev(bproj), dev(g2), dev(b2))
+    ops.attn_half_fwd(*args, x1d, xn2d, m1, r1, m2, r2, lsed, B, hw, C, shift, rowscale=dev(s1), xn1=xn1d, qkv=qkvd, o=od)
+    assert rel(m1, x.mean(1)) <= 1e-5 + 1e-4 and rel(r1, 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)) <= 1e-4
+    assert rel(xn1d, xn1) <= 8e-3, rel(xn1d, xn1)
+    assert rel(qkvd, qkv) <= 1.5e-2, rel(qkvd, qkv)
+    assert rel(od, o) <= 3e-2, rel(od, o)
+    assert rel(lsed, lse) <= 1e-2, rel(lsed, lse)
+    eb = ((x1d.double().cpu() - x1).abs().max() / branch.abs().max()).item()        # error against the BRANCH's scale
+    assert eb <= 3e-2, eb
+    assert rel(xn2d, xn2) <= 3e-2, rel(xn2d, xn2)
+    assert rel(m2, x1.mean(1)) <= 2e-2 and rel(r2, 1 / torch.sqrt(x1.var(1, unbiased=False) + 1e-5)) <= 2e-2
+    # ---- nothing saved: same x1 / xn2 / statistics
+    x1e, xn2e = f32(M, C), h16(M, C)
+    ops.attn_half_fwd(*args, x1e, xn2e, m1, r1, m2, r2, lsed, B, hw, C, shift, rowscale=dev(s1))
+    assert torch.equal(x1e, x1d) and torch.equal(xn2e, xn2d)
+    # ---- the launch chain it replaces (same bf16 storage points): LayerNorm -> q | k | v -> attention -> projection (+ norm2)
+    xn1u, qkvu, ou, x1u, xn2u = h16(M, C), h16(M, 3 * C), h16(M, C), f32(M, C), h16(M, C)
+    ops.layernorm_fwd(args[0], args[1], args[2], args[3], xn1u, m1, r1, hw, shift)
+    ops.linear_fwd(xn1u, args[4], args[5], qkvu, 1)
+    ops.winattn_fwd(qkvu, args[6], ou, B, hw, C, shift, 1, lse=f32(M, heads))
+    ops.linear_fwd(ou, args[7], args[8], x1u, 1, res=args[0], rowscale=dev(s1), rows_per_scale=hw * hw)
+    ops.layernorm_fwd(x1u, args[9], args[10], None, xn2u, m2, r2, hw, 0)
+    eu = ((x1d - x1u).abs().max() / branch.abs().max()).item()
+    assert eu <= 3e-2, eu
+    assert rel(xn2d.float(), xn2u.float()) <= 3e-2
