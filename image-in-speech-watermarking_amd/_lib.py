@@ -69,6 +69,8 @@ _SIGS = {
     "wm_dwconv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.POINTER(WmReduceJob), c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_attn_half_fusable": [c_i32, c_i32],
     "wm_attn_half_fwd": [c_f] * 22 + [c_i32, c_i32, c_i32, c_i32, c_f],
+    "wm_attn_half_bwd_scratch_floats": [c_i32, c_i32, c_i32, c_i32],
+    "wm_attn_half_bwd": [c_f] * 29 + [C.POINTER(WmReduceJob), c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_leff_fusable": [c_i32, c_i32],
     "wm_leff_fwd": [c_f] * 12 + [c_i32, c_i32, c_i32, c_f],
     "wm_leff_bwd_scratch_floats": [c_i32, c_i32, c_i32],

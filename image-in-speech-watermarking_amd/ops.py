@@ -175,6 +175,21 @@ def attn_half_fwd(x, g1, b1, mod, wqkv, bqkv, table, wproj, bproj, g2, b2, x1, x
                                ptr(lse), ptr(xn1), ptr(qkv), ptr(o), B, hw, Cc, shift, _stream()), "wm_attn_half_fwd")
 
 
+def attn_half_bwd(dxn2, dy, x1, mean2, rstd2, g2, x, mean1, rstd1, g1, qkv, o, lse, table, wproj, wqkvT, dx1h, dqkv, dx, dg2, db2, dg1,
+                  db1, dtable, B, hw, Cc, shift, scratch, rowscale=None, copy_scale=None, dxh=None, dmod=None, defer=None):
+    """The residual-stream backward of the attention half in ONE launch (csrc/attn_fused.hip): norm2 backward -> projection dX ->
+    window-attention backward -> q | k | v dX -> norm1 backward.  wqkvT: the transposed [C, 3C] bf16 copy of the q | k | v weight."""
+    for t in (dxn2, qkv, o, wproj, wqkvT, dx1h, dqkv, dxh):
+        if t is not None and t.dtype != torch.bfloat16:
+            raise ValueError("attn_half_bwd: dxn2, qkv, o, wproj, wqkvT, dx1h, dqkv, dxh are bfloat16 tensors (bf16 mode only)")
+    if scratch.numel() < lib.wm_attn_half_bwd_scratch_floats(B, hw, Cc, int(dmod is not None)):
+        raise ValueError("attn_half_bwd: scratch buffer too small")
+    check(lib.wm_attn_half_bwd(ptr(dxn2), ptr(dy), ptr(x1), ptr(mean2), ptr(rstd2), ptr(g2), ptr(rowscale), ptr(x), ptr(mean1),
+                               ptr(rstd1), ptr(g1), ptr(qkv), ptr(o), ptr(lse), ptr(table), ptr(wproj), ptr(wqkvT), ptr(copy_scale),
+                               ptr(dx1h), ptr(dqkv), ptr(dx), ptr(dxh), ptr(dg2), ptr(db2), ptr(dg1), ptr(db1), ptr(dmod), ptr(dtable),
+                               ptr(scratch), defer, B, hw, Cc, shift, _stream()), "wm_attn_half_bwd")
+
+
 def leff_fusable(hw, Cc):
     """Does the model route this block's LeFF through the fused kernels (csrc/leff_fused.hip)?  They are parity-green at every
     (hw, C <= 128) of the step but, measured on MI355X at B = 256 (scripts/leff_fused_bench.py, profiles/r04_leff_fused_bench_b256.txt),

@@ -139,6 +139,24 @@ int wm_attn_half_fwd(const float* x, const float* gamma1, const float* beta1, co
                      float* mean1, float* rstd1, float* mean2, float* rstd2, float* lse, void* xn1, void* qkv, void* o,
                      int32_t B, int32_t hw, int32_t C, int32_t shift, void* stream);
 
+/* The same half backward, between the two weight-gradient products, in one window-local launch:
+ *   dx1 = dy + norm2'(dxn2);  dO = (dx1 * rowscale) Wproj;  dq|dk|dv = window-attention backward (qkv, o, lse from the forward);
+ *   dxn1 = dq|dk|dv Wqkv;  dx = dx1 + norm1'(dxn1)
+ * replacing wm_layernorm_bwd (norm2), the projection's input-gradient product, wm_winattn_bwd, the q | k | v input-gradient
+ * product and wm_layernorm_bwd (norm1).  dxn2 [tokens, C] bf16 (gradient of the norm2 output), dy / x1 / x [tokens, C] fp32,
+ * wproj [C, C] bf16, wqkvT [C, 3C] bf16 = the TRANSPOSED q | k | v weight.  Written: dx1h = bf16(dx1 * rowscale) and dqkv (the
+ * operands of the two weight-gradient products), dx, and dxh = bf16(dx * copy_scale) if not NULL.  Accumulated through `scratch`
+ * (>= wm_attn_half_bwd_scratch_floats floats; per-workgroup partial sums reduced by wm_reduce_jobs, deferred into 6 entries
+ * when `defer` is given): dgamma2, dbeta2, dgamma1, dbeta1 [C], dmod [64, C] (or NULL), dbias_table [225, heads].          */
+int64_t wm_attn_half_bwd_scratch_floats(int32_t B, int32_t hw, int32_t C, int32_t has_mod);
+int wm_attn_half_bwd(const void* dxn2, const float* dy, const float* x1, const float* mean2, const float* rstd2,
+                     const float* gamma2, const float* rowscale /* [B] or NULL */, const float* x, const float* mean1,
+                     const float* rstd1, const float* gamma1, const void* qkv, const void* o, const float* lse,
+                     const float* bias_table, const void* wproj_bf16, const void* wqkvT_bf16, const float* copy_scale /* [B] or NULL */,
+                     void* dx1h, void* dqkv, float* dx, void* dxh /* or NULL */, float* dgamma2, float* dbeta2, float* dgamma1,
+                     float* dbeta1, float* dmod /* or NULL */, float* dbias_table, float* scratch, WmReduceJob* defer /* 6 entries or NULL */,
+                     int32_t B, int32_t hw, int32_t C, int32_t shift, void* stream);
+
 /* ---- LeFF as two fused kernels (blocks with C in {32, 64, 128}, bf16 storage) — model.py:695-714 + the residual / DropPath add of
  * :1016-1017.  Replaces, for those blocks, linear1 + wm_dwconv_fwd + linear2 (forward) and linear2's input gradient +
  * wm_dwconv_bwd + linear1's input gradient (backward); the two weight-gradient products stay on wm_gemm (fc2's reads the saved

@@ -70,7 +70,7 @@ def ref_winattn(qkv, table, B, hw, C, shift):
     return o.reshape(B * hw * hw, C), lse.reshape(B * hw * hw, heads)
 
 
-SHAPES = [(2, 8, 32, 0, False), (2, 16, 64, 4, True), (1, 16, 128, 4, False), (1, 64, 32, 4, True), (1, 32, 64, 0, False),
+SHAPES = [(2, 8, 32, 0, False), (2, 16, 64, 4, True), (1, 16, 128, 4, False), (1, 64, 32, 4, False), (1, 32, 64, 0, False),
           (3, 8, 128, 0, True), (1, 32, 128, 4, True)]
 
 
@@ -133,3 +133,87 @@ def test_attn_half_fwd(wm, B, hw, C, shift, use_mod):
     eu = ((x1d - x1u).abs().max() / branch.abs().max()).item()
     assert eu <= 3e-2, eu
     assert rel(xn2d.float(), xn2u.float()) <= 3e-2
+
+
+@pytest.mark.parametrize("B,hw,C,shift,use_mod", SHAPES)
+def test_attn_half_bwd(wm, B, hw, C, shift, use_mod):
+    """The fused residual-stream backward against float64 autograd of the same function, and against the five launches it replaces."""
+    ops = wm.ops
+    D = torch.float64
+    M, heads = B * hw * hw, C // 32
+    tag = f"b{B}_{hw}_{C}_{shift}"
+    x = synth_array("ax" + tag, (M, C)).to(D).requires_grad_()
+    g1 = (1 + 0.1 * synth_array("ag1" + tag, (C,))).to(D).requires_grad_()
+    b1 = (0.1 * synth_array("ab1" + tag, (C,))).to(D).requires_grad_()
+    g2 = (1 + 0.1 * synth_array("ag2" + tag, (C,))).to(D).requires_grad_()
+    b2 = (0.1 * synth_array("ab2" + tag, (C,))).to(D).requires_grad_()
+    mod = (0.5 * synth_array("am" + tag, (64, C))).to(D).requires_grad_() if use_mod else None
+    wqkv = bfr(synth_array("awq" + tag, (3 * C, C), 1.0 / math.sqrt(C))).to(D)
+    bqkv = (0.2 * synth_array("abq" + tag, (3 * C,))).to(D)
+    wproj = bfr(synth_array("awp" + tag, (C, C), 1.0 / math.sqrt(C))).to(D)
+    bproj = (0.2 * synth_array("abp" + tag, (C,))).to(D)
+    table = (0.5 * synth_array("at" + tag, (225, heads))).to(D).requires_grad_()
+    s1 = torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.8][:B], dtype=D)          # (B >= 2: one sample drops the branch)
+    cs = (torch.rand(B, generator=torch.Generator().manual_seed(4)) + 0.5).to(D)
+    srow = s1.repeat_interleave(hw * hw)[:, None]
+    dy = synth_array("ady" + tag, (M, C)).to(D)
+    dxn2 = bfr(synth_array("adn" + tag, (M, C))).to(D)
+    # ---- float64 autograd
+    xn1 = F.layer_norm(x, (C,), g1, b1)
+    if use_mod:
+        xn1 = xn1 + mod[window_pos(M, hw, shift)]
+    qkv = xn1 @ wqkv.t() + bqkv
+    qkv.retain_grad()
+    o, _ = ref_winattn(qkv, table, B, hw, C, shift)
+    x1 = x + (o @ wproj.t() + bproj) * srow
+    x1.retain_grad()
+    xn2 = F.layer_norm(x1, (C,), g2, b2)
+    ((x1 * dy).sum() + (xn2 * dxn2).sum()).backward()
+    # ---- kernels: the fused forward provides what the backward reads
+    f32 = lambda *s_: torch.empty(*s_, device="cuda")
+    z32 = lambda *s_: torch.zeros(*s_, device="cuda")
+    h16 = lambda *s_: torch.empty(*s_, device="cuda", dtype=BF)
+    x1d, xn2d = f32(M, C), h16(M, C)
+    m1, r1, m2, r2, lsed = f32(M), f32(M), f32(M), f32(M), f32(M, heads)
+    xn1d, qkvd, od = h16(M, C), h16(M, 3 * C), h16(M, C)
+    xd, modd = dev(x.detach()), (dev(mod.detach()) if use_mod else None)
+    wq16, wp16 = dev(wqkv, BF), dev(wproj, BF)
+    ops.attn_half_fwd(xd, dev(g1.detach()), dev(b1.detach()), modd, wq16, dev(bqkv), dev(table.detach()), wp16, dev(bproj),
+                      dev(g2.detach()), dev(b2.detach()), x1d, xn2d, m1, r1, m2, r2, lsed, B, hw, C, shift, rowscale=dev(s1),
+                      xn1=xn1d, qkv=qkvd, o=od)
+    wqT = wq16.t().contiguous()
+    dx1h, dqkvd, dxd, dxh = h16(M, C), h16(M, 3 * C), f32(M, C), h16(M, C)
+    dg2, db2, dg1, db1, dtab = z32(C), z32(C), z32(C), z32(C), z32(225, heads)
+    dmod = z32(64, C) if use_mod else None
+    scr = torch.empty(int(wm.lib.wm_attn_half_bwd_scratch_floats(B, hw, C, int(use_mod))), device="cuda")
+    ops.attn_half_bwd(dev(dxn2, BF), dev(dy), x1d, m2, r2, dev(g2.detach()), xd, m1, r1, dev(g1.detach()), qkvd, od, lsed,
+                      dev(table.detach()), wp16, wqT, dx1h, dqkvd, dxd, dg2, db2, dg1, db1, dtab, B, hw, C, shift, scr,
+                      rowscale=dev(s1), copy_scale=dev(cs), dxh=dxh, dmod=dmod)
+    assert rel(dx1h, x1.grad * srow) <= 1.5e-2, rel(dx1h, x1.grad * srow)
+    assert rel(dqkvd, qkv.grad) <= 6e-2, rel(dqkvd, qkv.grad)
+    branch = x.grad - x1.grad                                          # what the attention branch adds to the residual gradient
+    eb = ((dxd.double().cpu() - x.grad).abs().max() / branch.abs().max()).item()
+    assert eb <= 5e-2, eb
+    assert rel(dxh, x.grad * cs.repeat_interleave(hw * hw)[:, None]) <= 2e-2
+    assert rel(dg2, g2.grad) <= 1e-2 and rel(db2, b2.grad) <= 1e-2, (rel(dg2, g2.grad), rel(db2, b2.grad))
+    assert rel(dg1, g1.grad) <= 5e-2 and rel(db1, b1.grad) <= 5e-2, (rel(dg1, g1.grad), rel(db1, b1.grad))
+    assert rel(dtab, table.grad) <= 5e-2, rel(dtab, table.grad)
+    if use_mod:
+        assert rel(dmod, mod.grad) <= 5e-2, rel(dmod, mod.grad)
+    # ---- the five launches it replaces, on the same saved tensors
+    dx1u, dx1hu, dou, dqkvu, dxn1u, dxu = f32(M, C), h16(M, C), h16(M, C), h16(M, 3 * C), h16(M, C), f32(M, C)
+    dg2u, db2u, dg1u, db1u, dtabu = z32(C), z32(C), z32(C), z32(C), z32(225, heads)
+    dmodu = z32(64, C) if use_mod else None
+    ops.layernorm_bwd(dev(dxn2, BF), x1d, dev(g2.detach()), m2, r2, dev(dy), dx1u, dg2u, db2u, None, hw, 0, dx_bf16=dx1hu,
+                      copy_scale=dev(s1), rows_per_scale=hw * hw)
+    ops.linear_bwd_input(dx1hu, wp16, dou, 1)
+    ops.winattn_bwd(qkvd, dev(table.detach()), dou, dqkvu, dtabu, B, hw, C, shift, 1, out=od, lse=lsed)
+    ops.linear_bwd_input(dqkvu, wq16, dxn1u, 1)
+    ops.layernorm_bwd(dxn1u, xd, dev(g1.detach()), m1, r1, dx1u, dxu, dg1u, db1u, dmodu, hw, shift)
+    assert rel(dx1h.float(), dx1hu.float()) <= 1e-2                    # (row reductions in another order: a bf16 ulp here and there)
+    assert rel(dqkvd.float(), dqkvu.float()) <= 3e-2
+    eu = ((dxd - dxu).abs().max() / branch.abs().max()).item()
+    assert eu <= 3e-2, eu
+    assert rel(dtab, dtabu) <= 3e-2 and rel(dg1, dg1u) <= 3e-2
+    if use_mod:
+        assert rel(dmod, dmodu) <= 3e-2
