@@ -332,7 +332,8 @@ class UformerAudio(nn.Module):
         """Eight disjoint scratch slices for the deferred reductions of one LeWin block's backward (4 split-K GEMMs, 2
         LayerNorms, depthwise conv, attention bias table) + the host-side job list; one launch sums them all."""
         sizes = [int(ops.lib.wm_gemm_scratch_floats())] * 4 + [int(ops.lib.wm_layernorm_bwd_scratch_floats(C))] * 2 + \
-                [int(ops.lib.wm_dwconv_bwd_scratch_floats(B, hw, 4 * C)), int(ops.lib.wm_winattn_bwd_scratch_floats())]
+                [int(ops.lib.wm_dwconv_bwd_scratch_floats(B, hw, 4 * C)), int(ops.lib.wm_winattn_bwd_scratch_floats()),
+                 int(ops.lib.wm_attn_half_bwd_scratch_floats(B, hw, C, 1))]          # (0 where the fused attention half does not apply)
         sizes = [(n + 63) // 64 * 64 for n in sizes]
         buf = getattr(self, "_blk_scr", None)
         if buf is None or buf.device != dev or buf.numel() < sum(sizes):
@@ -538,7 +539,7 @@ class UformerAudio(nn.Module):
         P, G, dev, mode = self._views, self._gviews, x.device, self._mode()
         M, N = x.shape[0], hw * hw
         # every small-gradient reduction of the block (4 split-K, 2 LN, depthwise, bias table) is deferred into one launch
-        (sg0, sg1, sg2, sg3, sl0, sl1, sdw, sat), jobs = self._block_scratch(dev, B, hw, C)
+        (sg0, sg1, sg2, sg3, sl0, sl1, sdw, sat, sab), jobs = self._block_scratch(dev, B, hw, C)
         # LeFF
         H, W = self._H, self._W
         half = self.compute_mode == "bf16"
@@ -565,6 +566,24 @@ class UformerAudio(nn.Module):
             ops.linear_bwd_input(dh1, W(pre + "mlp.linear1.0.weight"), dxn2, mode, wT=WT(pre + "mlp.linear1.0.weight"))
         ops.linear_bwd_weight(dh1, xn2, G[pre + "mlp.linear1.0.weight"], G[pre + "mlp.linear1.0.bias"], mode, scratch=sg1,
                               defer=jobs.take(1))
+        if half and ops.attn_half_fusable(hw, C):
+            # C <= 128: norm2' -> projection dX -> window-attention backward -> q | k | v dX -> norm1' as ONE window-local launch
+            # (csrc/attn_fused.hip); the two weight-gradient products read the bf16 tensors it writes (dx1h carries s1)
+            wqT = H(dev, C, 3 * C)
+            ops.strided3(P[pre + "attn.qkv.w"], wqT, (C, 3 * C, 1), (1, C, 0), (3 * C, 1, 0))
+            dx1h, dqkv, dx, dxh = H(dev, M, C), H(dev, M, 3 * C), _E(dev, M, C), H(dev, M, C)
+            ops.attn_half_bwd(dxn2, dy, x1, mean2, rstd2, P[pre + "norm2.weight"], x, mean1, rstd1, P[pre + "norm1.weight"], qkv, o, lse,
+                              P[pre + "attn.relative_position_bias_table"], W(pre + "attn.proj.weight"), wqT, dx1h, dqkv, dx,
+                              G[pre + "norm2.weight"], G[pre + "norm2.bias"], G[pre + "norm1.weight"], G[pre + "norm1.bias"],
+                              G[pre + "attn.relative_position_bias_table"], B, hw, C, shift, sab, rowscale=s1,
+                              copy_scale=consumer_scale, dxh=dxh, dmod=G[pre + "modulator.weight"] if mod else None,
+                              defer=jobs.take(6))
+            ops.linear_bwd_weight(dx1h, o, G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], mode, scratch=sg2, defer=jobs.take(1))
+            ops.linear_bwd_weight(dqkv, xn1, G[pre + "attn.qkv.w"], G[pre + "attn.qkv.b"], mode, scratch=sg3, defer=jobs.take(1))
+            ops.reduce_jobs(jobs)
+            if self._grad_ready is not None:
+                self._grad_ready(*self._owner_range[pre])          # this block's gradients are final
+            return dx, dxh
         dx1 = _E(dev, M, C)
         dx1h = H(dev, M, C) if half else None
         # the bf16 copy of dx1 feeds the two proj products only, both of which want dx1 * s1

@@ -40,6 +40,11 @@ COST = {
     "winattn_bwd": lambda qkv, t, do, dq, dt, B, hw, C, sh, mode, out=None, lse=None, scratch=None, defer=None: (_attn_cost(B, hw, C, 6), qkv.element_size() * B * hw * hw * 8.0 * C),   # q|k|v, dO, O read; dq|dk|dv written
     "dwconv_fwd": lambda h1, w, b, h2, B, hw, Ch, a2=None, g2=None: (18.0 * B * hw * hw * Ch, (1.0 + sum(t is not None for t in (h2, a2, g2))) * h1.element_size() * B * hw * hw * Ch),
     "dwconv_bwd": lambda h1, d, w, dh, dw, db, B, hw, Ch, scratch=None, defer=None: (54.0 * B * hw * hw * Ch, 3.0 * h1.element_size() * B * hw * hw * Ch),
+    # fused attention half (C <= 128): q|k|v + proj products (8 C^2 MAC per token) + the window attention; forward reads x, writes x1 +
+    # xn2 (+ xn1, q|k|v, o for the backward); backward reads dxn2, dy, x1, q|k|v, o, x and writes dx1h, dq|dk|dv, dx, dxh
+    "attn_half_fwd": lambda x, g1, b1, mod, wq, bq, tb, wp, bp, g2, b2, x1, *a, **k:
+        (8.0 * x.numel() * x.shape[1] + 256.0 * x.numel(), x.numel() * (10.0 + (10.0 if k.get("qkv") is not None else 0.0))),
+    "attn_half_bwd": lambda dxn2, dy, *a, **k: (16.0 * dy.numel() * dy.shape[1] + 640.0 * dy.numel(), dy.numel() * 36.0),
     # fused LeFF (C <= 128): two [tokens x C x 4C] products + the depthwise taps; xn2 / dy read, x1 read, x2 / dxn2 written, the two
     # saved pre-activations written (forward) or read (backward) and dh1 written (halo re-reads are L2 traffic, not algorithmic)
     "leff_fwd": lambda xn2, x1, w1, b1, wd, bd, w2, b2, x2, B, hw, C, rowscale=None, h1=None, h2=None:

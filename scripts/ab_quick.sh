@@ -1,6 +1,6 @@
 #!/bin/bash
 # Quick interleaved A/B of one environment toggle at the bench batch: bash scripts/ab_quick.sh VAR [rounds] [extra bench args]
-V=$1; R=${2:-2}; shift; shift
+V=$1; R=${2:-2}; shift; shift || true
 QUIET="--no-cpu-baseline --no-kernel-timing --no-identity-leg --no-parity-mode-leg --no-secondary-legs --ber-train-steps 0"
 for r in $(seq 1 $R); do
   for on in 0 1; do

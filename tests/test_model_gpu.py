@@ -310,7 +310,9 @@ def test_reference_lr_schedule_drives_fused_adamw_under_graph_replay(wm):
             ref.step()
             moved = (m._flat[:n] - before).abs().mean().item()
             err = (m._flat[:n] - shadow.detach()).abs().max().item()
-            assert moved > 0.2 * lrs[-1] and err <= 2e-6, (epoch, lrs[-1], moved, err)
+            # (AdamW moves an element by lr * m / (sqrt(v) + eps): ~lr at the first step, a fraction of it once the gradient signs
+            # fluctuate; a replay that kept an OLD learning rate would be off by the difference of two epochs' rates, >= 3e-5)
+            assert moved > 0.05 * lrs[-1] and err <= 2e-6, (epoch, lrs[-1], moved, err)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             s_hip.step()
