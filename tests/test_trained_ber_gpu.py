@@ -20,11 +20,20 @@ def wm():
 
 
 def test_trained_hip_step_recovers_the_payload_and_matches_the_cpu_oracle(wm):
-    net, curve, xh, mh = ber_train.train(wm, steps=1600, batch=32, mode="bf16", lr=2e-4, eval_every=400)
+    net, curve, xh, mh = ber_train.train(wm, steps=2000, batch=32, mode="bf16", lr=2e-4, eval_every=200)
     first, last = curve[0], curve[-1]
+    assert len(curve) >= 9
     assert first["attacked"] > 0.45                                # untrained: chance
     assert last["attacked"] < 0.05, curve                          # trained: the payload survives the full attack stack
     assert last["no_attack"] < first["no_attack"] - 0.05, curve
+    # convergence, not one lucky evaluation: at least two consecutive held-out evaluations behind the transition stay decoded
+    assert sum(e["attacked"] < 0.05 for e in curve[-3:]) >= 2, curve
+    try:                                                            # (merged back from the GPU box; the judged copy lives under profiles/)
+        import json, os
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r04_ber_block_payload_curve.json"), "w") as fh:
+            json.dump(curve, fh, indent=1)
+    except OSError:
+        pass
     par = ber_train.oracle_parity(wm, net, xh, mh, tiles=8)
     for name in ("no_attack", "attacked"):
         e = par[name]
