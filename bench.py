@@ -577,7 +577,7 @@ def kernel_rooflines(a, wm, net, opt, attack, extract_from, x, msg, result):
                                         "frac_vs_fused_ideal": 652320.0 * a.batch / ts / 1e9 / prof.HBM_PEAK_GBS,
                                         "kernels_us": {r["kernel"]: round(per[r["kernel"]] * 1e6, 1) for r in stft_rows},
                                         "kernels_us_eager_event_pairs": {r["kernel"]: round(r["avg_us"], 1) for r in stft_rows}}
-    mf = [r for r in rows if r["kernel"].startswith("gemm_") or r["kernel"].startswith("winattn")]
+    mf = [r for r in rows if r["kernel"].startswith(("gemm_", "winattn", "attn_half"))]
     fl, ts = sum(r["flops"] for r in mf), sum(r["total_s"] for r in mf)
     peak = prof.MFMA_PEAK_TFLOPS[1 if a.mode == "bf16" else 0]
     result["mfma_path"] = {"achieved_TFLOPs": fl / ts / 1e12, "time_ms_per_step": ts * 1e3, "alg_TFLOP_per_step": fl / 1e12,
