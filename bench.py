@@ -51,6 +51,8 @@ def parse_args():
                          "bit-exact bound (fp32 MFMA; fp32 storage with every GEMM as three bf16 MFMA products of hi / lo halves)")
     ap.add_argument("--no-parity-mode-leg", action="store_true", help="skip the extra measurement of the tolerance-meeting 'split' mode")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--grad-exchange", default="fp32", choices=["fp32", "bf16"],
+                    help="N > 1: how the gradient buckets cross xGMI: fp32 all-reduce, or bf16 all-gather with fp32 accumulation on arrival")
     ap.add_argument("--segmented", action="store_true",
                     help="capture the step as the multi-rank chain of graphs (cut at the gradient buckets) on one rank too")
     ap.add_argument("--no-secondary-legs", action="store_true", help="skip the config-5 (10 s clips) and fp32-mode rates")
@@ -354,7 +356,7 @@ def main():
         ber = cpu_baseline_parity(wm, net, x, msg)               # before any optimiser step: weights = the synthetic init
 
     step = wm.TrainStep(net, opt, a.batch, attack=attack, extract_from=extract_from, use_graph=not a.no_graph,
-                        segmented=a.segmented)
+                        segmented=a.segmented, grad_exchange=a.grad_exchange)
 
     def barrier():
         if world > 1:
@@ -393,9 +395,11 @@ def main():
         step.sync.timing = None
         # bus bandwidth of a ring all-reduce: 2 (N - 1) / N x bytes / time; one xGMI link carries ~153 GB/s per direction pair
         # (MI355X_MICROARCH / SURVEY 5), so a ring is bound by that per link
-        allreduce = {"buckets_in_launch_order": [
+        wire = 2 if a.grad_exchange == "bf16" else 4              # bytes per gradient element on the links
+        allreduce = {"exchange": a.grad_exchange + (" (all-gather of the ranks' bf16-rounded buckets, fp32 sum on arrival)" if wire == 2 else " all-reduce"),
+                     "buckets_in_launch_order": [
             {"MB": round((hi - lo) * 4 / 1e6, 1), "ms": round(statistics.median(t), 3),
-             "bus_GBps": round(2 * (world - 1) / world * (hi - lo) * 4 / (statistics.median(t) * 1e-3) / 1e9, 1)}
+             "bus_GBps": round((1 if wire == 2 else 2) * (world - 1) / world * (hi - lo) * wire / (statistics.median(t) * 1e-3) / 1e9, 1)}
             for (lo, hi), t in per.items()],
             "xgmi_link_GBps": 153, "bucket_target_MB": round(step.sync.bucket_elems * 4 / 2 ** 20, 1),
             "exposed_tail_MB": round(sum((hi - lo) for (lo, hi) in list(per)[-2:]) * 4 / 1e6, 1)}

@@ -82,6 +82,7 @@ _SIGS = {
     "wm_copy_cols": [c_f, c_i64, c_i32, c_f, c_i64, c_i32, c_i64, c_i32, c_i32, c_f],
     "wm_strided3": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_f],
     "wm_cast_bf16": [c_f, c_f, c_i64, c_f],
+    "wm_sum_bf16_rows": [c_f, c_f, c_i32, c_i64, c_f],
     "wm_transpose_cast_jobs": [c_f, c_f, c_f, c_i32, c_i32, c_f],
     "wm_minmax_scratch_floats": [],
     "wm_minmax": [c_f, c_i64, c_f, c_f, c_f],

@@ -242,6 +242,21 @@ inline unsigned grid_for(int64_t total) {
 }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// dst[i] = sum over r of float(src[r][i]): the data-parallel gradient exchange in bf16 (train.GradSync(exchange="bf16")) gathers every
+// rank's bf16-rounded bucket and accumulates them HERE in fp32, in rank order on every rank (replicas stay bit-identical)
+__global__ __launch_bounds__(256) void sum_bf16_rows_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, int rows, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= n) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < rows; ++r) {
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)r * n + i);
+    acc[0] += bf_lo(v.x); acc[1] += bf_hi(v.x); acc[2] += bf_lo(v.y); acc[3] += bf_hi(v.y);
+    acc[4] += bf_lo(v.z); acc[5] += bf_hi(v.z); acc[6] += bf_lo(v.w); acc[7] += bf_hi(v.w);
+  }
+  *reinterpret_cast<float4*>(dst + i) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *reinterpret_cast<float4*>(dst + i + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
 }  // namespace
 
 extern "C" int wm_im2col_4x4s2(const float* x, void* cols, int32_t cols_bf16, int32_t B, int32_t hw, int32_t C,
@@ -366,6 +381,13 @@ extern "C" int wm_cast_bf16(const float* src, void* dst, int64_t n, void* stream
   if (!src || !dst || n <= 0 || (n & 3) || !al16(src)) return WM_EINVAL;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), src,
                      static_cast<__bf16*>(dst), n / 4);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+extern "C" int wm_sum_bf16_rows(const void* src_bf16, float* dst, int32_t rows, int64_t n, void* stream) {
+  if (!src_bf16 || !dst || rows <= 0 || n <= 0 || (n & 7)) return WM_EINVAL;
+  hipLaunchKernelGGL(sum_bf16_rows_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const __bf16*>(src_bf16), dst, rows, n);
   WM_CHECK_LAUNCH();
   return WM_OK;
 }

@@ -251,6 +251,11 @@ def cast_bf16(src, dst, n):
     check(lib.wm_cast_bf16(ptr(src), ptr(dst), n, _stream()), "wm_cast_bf16")
 
 
+def sum_bf16_rows(src, dst, rows, n):
+    """dst[i] (fp32) = sum over the `rows` bf16 rows of src[r, i]."""
+    check(lib.wm_sum_bf16_rows(ptr(src), ptr(dst), rows, n, _stream()), "wm_sum_bf16_rows")
+
+
 def transpose_cast_jobs(arena, arena_t, jobs, njobs, total_tiles):
     """bf16 transposes of the job list's matrices (same offsets in both arenas), one launch."""
     check(lib.wm_transpose_cast_jobs(ptr(arena), ptr(arena_t), ptr(jobs), njobs, total_tiles, _stream()), "wm_transpose_cast_jobs")

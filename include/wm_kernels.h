@@ -194,6 +194,9 @@ int wm_strided3(const float* in, void* out, int32_t out_bf16, int32_t n0, int32_
                 int64_t si1, int64_t si2, int64_t so0, int64_t so1, int64_t so2, int32_t atomic, void* stream);
 /* bf16 copy of (a slice of) the fp32 parameter arena: the B operands of the forward / dX GEMMs in bf16 mode */
 int wm_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst[i] = sum_r float(src[r * n + i]), r < rows (n a multiple of 8): fp32 accumulation of the ranks' bf16-rounded gradient buckets
+ * (data-parallel exchange in bf16: the reference is single-device; train.GradSync(exchange="bf16")) */
+int wm_sum_bf16_rows(const void* src_bf16, float* dst, int32_t rows, int64_t n, void* stream);
 /* Range-style audio_scale ("lo-hi") of the reference's data preparation and evaluation loop: min / max over the whole tile
  * tensor (normalize_batch, audio_test.py:33-55) left on the device, and the affine map of a tensor into [lo, hi] with those
  * statistics (audio_test.py:331-338, :698-702) or back (inverse != 0; audio_test.py:567-571).

@@ -101,7 +101,8 @@ net = wm.UformerAudio(modulator=True)
 g = torch.Generator().manual_seed(100 + rank)
 net._flat_grad.copy_(torch.randn(net._flat_grad.numel(), generator=g))
 mine = net._flat_grad.clone()
-sync = wm.GradSync(net)
+xmode = sys.argv[4] if len(sys.argv) > 4 else "fp32"
+sync = wm.GradSync(net, exchange=xmode)
 sent = []
 orig = sync.all_reduce
 sync.all_reduce = lambda lo, hi: (sent.append((lo, hi)), orig(lo, hi))
@@ -123,7 +124,12 @@ for idx, owners in enumerate((trunk("decoder_wm."), dec, trunk("encoder."))):
 sync.finish()
 other = torch.randn(net._flat_grad.numel(), generator=torch.Generator().manual_seed(100 + (1 - rank)))
 n = net.optimized_numel
-assert torch.allclose(net._flat_grad[:n], (mine + other)[:n]), "every element of the optimised arena is all-reduced exactly once"
+if xmode == "bf16":                        # each rank's contribution rounded to bf16 once, the sum taken in fp32 in rank order
+    r0, r1 = (mine, other) if rank == 0 else (other, mine)
+    want = r0.bfloat16().float() + r1.bfloat16().float()
+    assert torch.equal(net._flat_grad[:n], want[:n]), "bf16 exchange: fp32 sum of the ranks' bf16-rounded buckets, identical on every rank"
+else:
+    assert torch.allclose(net._flat_grad[:n], (mine + other)[:n]), "every element of the optimised arena is all-reduced exactly once"
 assert torch.equal(net._flat_grad[n:], mine[n:]), "the unused tail is never exchanged"
 sizes = [(hi - lo) * 4 / 2 ** 20 for lo, hi in sent]
 assert len(sent) >= 10 and max(sizes) < 45, sizes                      # ~25 MB buckets, not three 69 / 136 / 69 MB slices
@@ -133,11 +139,12 @@ print("rank", rank, "ok")
 """
 
 
-def test_gradsync_two_ranks_gloo(wm, tmp_path):
+@pytest.mark.parametrize("xmode", ["fp32", "bf16"])
+def test_gradsync_two_ranks_gloo(wm, tmp_path, xmode):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
-    port = str(29500 + os.getpid() % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), port], stdout=subprocess.PIPE,
+    port = str(29500 + (os.getpid() + (7 if xmode == "bf16" else 0)) % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), port, xmode], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)

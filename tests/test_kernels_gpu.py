@@ -844,6 +844,21 @@ def test_payload_quadrant_tiling_roundtrip(wm):
 
 
 # ------------------------------------------------------------------------------------------- deferred reductions
+def test_sum_bf16_rows(wm):
+    """fp32 accumulation of the ranks' bf16 gradient buckets (train.GradSync(exchange='bf16')): exact on bf16 inputs."""
+    ops = wm.ops
+    rows, n = 5, 8 * 1031
+    src = torch.randn(rows, n, device="cuda").bfloat16()
+    dst = torch.empty(n, device="cuda")
+    ops.sum_bf16_rows(src, dst, rows, n)
+    want = torch.zeros(n, device="cuda")
+    for r in range(rows):
+        want += src[r].float()
+    assert torch.equal(dst, want)
+    with pytest.raises(wm._lib.WmKernelError):
+        ops.sum_bf16_rows(src, dst, rows, n - 3)
+
+
 def test_deferred_reductions_match_immediate_ones(wm):
     """wm_reduce_jobs: LayerNorm / depthwise / bias-table / split-K producers defer their partial-sum reductions into one
     launch; gradients must equal the immediate (scratch + own reduce kernel) results."""
