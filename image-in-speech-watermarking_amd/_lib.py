@@ -100,18 +100,18 @@ _SIGS = {
     "wm_stft255_tiles": [c_f, c_i64, c_i32, c_f, c_fl, c_f],
     "wm_istft255_stitch": [c_f, c_i32, c_i32, c_i32, c_f, c_i64, c_fl, c_f],
     "wm_wave_attack": [C.POINTER(WmWaveAttack), c_f, c_f, c_i64, c_i32, c_f, c_f],
-    "wm_stft255_table_bytes": [],
-    "wm_stft255_tables": [c_f, c_f],
+    "wm_stft255_table_bytes": [c_i32],
+    "wm_stft255_tables": [c_f, c_i32, c_f],
     "wm_wave_lowpass": [c_f, c_f, c_f, c_i64, c_i32, c_f, c_i32, c_f],
     "wm_wave_resample": [c_f, c_f, c_f, c_i64, c_i32, c_f, c_i32, c_f],
     "wm_pv_frames": [c_i64],
     "wm_pv_steps": [c_i64, C.c_double],
     "wm_time_stretch": [c_f, c_i64, c_i32, C.c_double, c_f, c_f, c_f, c_f, c_i64, c_f],
     "wm_sinc_resample": [c_f, c_i64, c_i32, C.c_double, c_f, c_f, c_i32, c_i32, c_f, c_i64, c_f],
-    "wm_istft255_fwd": [c_f, c_f, c_f, c_i32, c_f],
-    "wm_stft255_fwd": [c_f, c_f, c_f, c_i32, c_f],
-    "wm_istft255_bwd": [c_f, c_f, c_f, c_i32, c_f],
-    "wm_stft255_bwd": [c_f, c_f, c_f, c_i32, c_f],
+    "wm_istft255_fwd": [c_f, c_f, c_f, c_i32, c_i32, c_f],
+    "wm_stft255_fwd": [c_f, c_f, c_f, c_i32, c_i32, c_f],
+    "wm_istft255_bwd": [c_f, c_f, c_f, c_i32, c_i32, c_f],
+    "wm_stft255_bwd": [c_f, c_f, c_f, c_i32, c_i32, c_f],
     "wm_attack_fir_table_bytes": [],
     "wm_attack_fir_tables": [c_f, c_i32, c_f, c_f],
     "wm_attack_fwd": [C.POINTER(WmAttack), c_f, c_f, c_f, c_i32, c_i32, c_f],

@@ -132,25 +132,27 @@ def _device_tables(device):
     return _tables[key]
 
 
-def _desc(cfg, device, step):
+def _desc(cfg, device, step, precise=False):
+    """precise: the two low-pass passes as scalar fp32 loops instead of split-precision MFMA products (1e-7 instead of 4e-6 .. 2e-5
+    of full scale each; the fp32 / split compute modes ask for it)."""
     lp, rs, fir = _device_tables(device)
     delay, gain = cfg.echo if cfg.echo is not None else (0, 0.0)
     return WmAttack(cfg.flags, float(cfg.snr_db or 0.0), float(cfg.amp if cfg.amp is not None else 1.0), ptr(lp),
                     LP_TAPS, ptr(rs), 41, rank_seed(cfg.seed), ptr(step), int(delay), float(gain), int(cfg.jitter or 0), 0,
-                    ptr(fir) if cfg.mfma_fir else None)
+                    ptr(fir) if (cfg.mfma_fir and not precise) else None)
 
 
-def attack_forward(cfg, wave, step, out=None, sigma=None):
+def attack_forward(cfg, wave, step, out=None, sigma=None, precise=False):
     B, L = wave.shape
     out = torch.empty_like(wave) if out is None else out
     if sigma is None:
         sigma = torch.empty(B, device=wave.device, dtype=torch.float32)
-    ops.attack_fwd(_desc(cfg, wave.device, step), wave, out, sigma, B, L)
+    ops.attack_fwd(_desc(cfg, wave.device, step, precise), wave, out, sigma, B, L)
     return out, sigma
 
 
-def attack_backward(cfg, wave, dout, sigma, step, dwave=None):
+def attack_backward(cfg, wave, dout, sigma, step, dwave=None, precise=False):
     B, L = wave.shape
     dwave = torch.empty_like(wave) if dwave is None else dwave
-    ops.attack_bwd(_desc(cfg, wave.device, step), wave, dout, sigma, dwave, B, L)
+    ops.attack_bwd(_desc(cfg, wave.device, step, precise), wave, dout, sigma, dwave, B, L)
     return dwave

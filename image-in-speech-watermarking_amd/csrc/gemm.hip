@@ -577,7 +577,7 @@ int wm_gemm_big_tn_bf16(const WmGemm& g, hipStream_t st); // ... its weight-grad
 
 thread_local int wm_gemm_family_tls = WM_FAM_GENERIC;
 extern "C" int32_t wm_last_gemm_family(void) { return wm_gemm_family_tls; }
-extern "C" int wm_abi_version(void) { return 6; }
+extern "C" int wm_abi_version(void) { return 7; }
 // split-K slices of one weight-gradient launch: the 128 x 128 kernel writes up to ~384 tiles, the 256 x 256 kernel one tile
 // per CU (256 x 65536 floats = 67 MB)
 extern "C" int64_t wm_gemm_scratch_floats(void) { return 256LL * 256 * 256 + 1024 * 1024; }

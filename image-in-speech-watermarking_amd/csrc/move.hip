@@ -145,8 +145,9 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restri
 }
 
 // Transposed bf16 copies of many [rows, cols] fp32 matrices of one arena in ONE launch (the dX GEMMs of the big-tile kernel
-// read their weights K-contiguous: gemm_big.hip).  job = {element offset of the matrix in both arenas, rows, cols, first
-// tile}; a workgroup moves one 64 x 64 tile through LDS (256-byte row reads, 128-byte row writes).
+// read their weights K-contiguous: gemm_big.hip; the fused attention-half backward reads Wqkv^T: attn_fused.hip).  job =
+// {element offset of the matrix in both arenas, rows, cols, first tile}; a workgroup moves one 64 x 64 tile through LDS
+// (256-byte row reads, 128-byte row writes); rows, cols: multiples of 4, edge tiles are partial.
 __global__ __launch_bounds__(256) void transpose_cast_jobs_kernel(const float* __restrict__ src, __bf16* __restrict__ dst,
                                                                   const int4* __restrict__ jobs, int njobs) {
   __shared__ float tile[64][65];
@@ -156,12 +157,13 @@ __global__ __launch_bounds__(256) void transpose_cast_jobs_kernel(const float* _
     if (jobs[mid].w <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const int4 jb = jobs[lo];
-  const int rows = jb.y, cols = jb.z, tc = cols / 64, t = blockIdx.x - jb.w, r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+  const int rows = jb.y, cols = jb.z, tc = (cols + 63) / 64, t = blockIdx.x - jb.w, r0 = (t / tc) * 64, c0 = (t % tc) * 64;
   const float* s = src + jb.x + (int64_t)r0 * cols + c0;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;        // 16 threads x float4 per row, 16 rows per sweep
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float4 v = *reinterpret_cast<const float4*>(s + (int64_t)(ty + 16 * q) * cols + 4 * tx);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + ty + 16 * q < rows && c0 + 4 * tx < cols) v = *reinterpret_cast<const float4*>(s + (int64_t)(ty + 16 * q) * cols + 4 * tx);
     tile[ty + 16 * q][4 * tx] = v.x; tile[ty + 16 * q][4 * tx + 1] = v.y; tile[ty + 16 * q][4 * tx + 2] = v.z; tile[ty + 16 * q][4 * tx + 3] = v.w;
   }
   __syncthreads();
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void transpose_cast_jobs_kernel(const float* _
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c = ty + 16 * q;
+    if (c0 + c >= cols || r0 + 4 * tx >= rows) continue;
     const float4 v = make_float4(tile[4 * tx][c], tile[4 * tx + 1][c], tile[4 * tx + 2][c], tile[4 * tx + 3][c]);
     IO<__bf16>::st4(d + (int64_t)c * rows + 4 * tx, v);
   }

@@ -8,9 +8,13 @@
 //   synthesis  E[n] = sum_k Xr[k] c[k][n],  O[n] = sum_k Xi[k] s[k][n],  frame[n] = E - O, frame[255 - n] = E + O
 //   analysis   u[n] = x[n] + x[255 - n], v[n] = x[n] - x[255 - n],  Re[k] = sum_n u[n] c[k][n], Im[k] = -sum_n v[n] s[k][n]
 // i.e. two [128 x 128] x [128 x frames] products per tile and direction with ONE symmetric pair of tables, which run on
-// v_mfma_f32_32x32x16_bf16 in split precision: x = hi + lo (two bf16), table = hi + lo, product = hi*hi + hi*lo + lo*hi
-// (the dropped lo*lo term is 2^-18 relative; measured max error 2e-6 of full scale against torch.stft / istft, the
-// fp32 MFMA form would run at 1/16 of the rate).  Overlap-add, envelope normalisation, centre trim, reflect padding
+// v_mfma_f32_32x32x16_bf16 in split precision, NS bf16 terms per operand:
+//   NS = 2 (the bf16 compute mode): x = hi + lo, table = hi + lo, product = hi*hi + hi*lo + lo*hi (operands carry 16 significant
+//           bits, the dropped lo*lo term is 2^-18 relative; measured max error 2e-6 of full scale against torch.stft / istft)
+//   NS = 3 (the fp32 / split compute modes, whose outputs are held to 1e-4 of the CPU oracle BEHIND the extractor network):
+//           x = hi + mid + lo (24 bits), product = hh + hm + mh + mm + hl + lh (dropped terms 2^-24 relative): fp32-grade, at
+//           twice the MFMA work of a path that is 0.1 % of the step
+// (the fp32 MFMA form would run at 1/16 of the rate).  Overlap-add, envelope normalisation, centre trim, reflect padding
 // and their adjoints are epilogues / prologues on the LDS image, so a tile costs one read of its input and one write of
 // its output (algorithmic 163 080 B per tile and transform).
 //
@@ -31,7 +35,8 @@ constexpr int SYN_GROUPS = 5;                          // 5 * 28 = 140 >= 132 sl
 constexpr int LDF = 257;                               // frame image row stride (floats): odd -> conflict-free column writes
 constexpr int SPAN = HOP * (FT - 1) + NFFT;            // 2208 samples staged per analysis workgroup
 constexpr int LDU = 136;                               // folded-frame image row stride (bf16): 272 B = 4 mod 64 words
-constexpr int TAB_ELEMS = 2 * 2 * 4 * 8 * 64 * 8;      // [cos|sin][hi|lo][row tile][k step][lane][8]
+constexpr int TAB_PLANE = 4 * 8 * 64 * 8;              // [row tile][k step][lane][8]
+constexpr int tab_elems(int NS) { return 2 * NS * TAB_PLANE; }   // [cos|sin][term][row tile][k step][lane][8]
 
 __device__ __forceinline__ int frames_covering(int q) {
   int thi = q / HOP;
@@ -41,37 +46,44 @@ __device__ __forceinline__ int frames_covering(int q) {
   return thi - tlo + 1;
 }
 
-__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
-  hi = (__bf16)x;
-  lo = (__bf16)(x - (float)hi);
+template <int NS>
+__device__ __forceinline__ void split_terms(float x, __bf16 (&p)[NS]) {
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    p[i] = (__bf16)x;
+    x -= (float)p[i];                                          // exact: the remainder fits fp32
+  }
 }
 
-// table entry (tbl, part) of row r, column c, in operand order for v_mfma_f32_32x32x16_bf16 A fragments:
+// table entry (tbl, term) of row r, column c, in operand order for v_mfma_f32_32x32x16_bf16 A fragments:
 // lane (r & 31, h) of row tile r >> 5 holds columns 16 ks + 8 h + j
+template <int NS>
 __global__ __launch_bounds__(256) void stft_table_kernel(__bf16* __restrict__ tab) {
   const int id = blockIdx.x * 256 + threadIdx.x;              // one (row tile, k step, lane, j) per thread
-  if (id >= 4 * 8 * 64 * 8) return;
+  if (id >= TAB_PLANE) return;
   const int j = id & 7, lane = (id >> 3) & 63, ks = (id >> 9) & 7, i = id >> 12;
   const int r = 32 * i + (lane & 31), c = 16 * ks + 8 * (lane >> 5) + j;
   double sn, cs;
   sincospi(2.0 * (double)((r * c) % NFFT) / (double)NFFT, &sn, &cs);
-  __bf16 h, l;
-  split_bf16((float)cs, h, l);
-  tab[(0 * 2 + 0) * 16384 + id] = h;
-  tab[(0 * 2 + 1) * 16384 + id] = l;
-  split_bf16((float)sn, h, l);
-  tab[(1 * 2 + 0) * 16384 + id] = h;
-  tab[(1 * 2 + 1) * 16384 + id] = l;
+  __bf16 t[NS];
+  split_terms<NS>((float)cs, t);
+#pragma unroll
+  for (int u = 0; u < NS; ++u) tab[(0 * NS + u) * TAB_PLANE + id] = t[u];
+  split_terms<NS>((float)sn, t);
+#pragma unroll
+  for (int u = 0; u < NS; ++u) tab[(1 * NS + u) * TAB_PLANE + id] = t[u];
 }
 
-struct TabFrags { bf16x8 ch, cl, sh, sl; };
-__device__ __forceinline__ TabFrags load_tab(const __bf16* __restrict__ tab, int i, int ks, int lane) {
+template <int NS> struct TabFrags { bf16x8 c[NS], s[NS]; };
+template <int NS>
+__device__ __forceinline__ TabFrags<NS> load_tab(const __bf16* __restrict__ tab, int i, int ks, int lane) {
   const int off = ((i * 8 + ks) * 64 + lane) * 8;
-  TabFrags t;
-  t.ch = *reinterpret_cast<const bf16x8*>(tab + 0 * 16384 + off);
-  t.cl = *reinterpret_cast<const bf16x8*>(tab + 1 * 16384 + off);
-  t.sh = *reinterpret_cast<const bf16x8*>(tab + 2 * 16384 + off);
-  t.sl = *reinterpret_cast<const bf16x8*>(tab + 3 * 16384 + off);
+  TabFrags<NS> t;
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    t.c[u] = *reinterpret_cast<const bf16x8*>(tab + (0 * NS + u) * TAB_PLANE + off);
+    t.s[u] = *reinterpret_cast<const bf16x8*>(tab + (1 * NS + u) * TAB_PLANE + off);
+  }
   return t;
 }
 
@@ -86,10 +98,17 @@ __device__ __forceinline__ bf16x8 tr_frag32(const __bf16* img, int ks, int lane)
   return f;
 }
 
-__device__ __forceinline__ void mma3(f32x16& acc, const bf16x8& th, const bf16x8& tl, const bf16x8& xh, const bf16x8& xl) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, xh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, xl, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl, xh, acc, 0, 0, 0);
+// acc += (sum t) (sum x) without the terms below 2^-8NS: the small products first
+template <int NS>
+__device__ __forceinline__ void mma_split(f32x16& acc, const bf16x8 (&t)[NS], const bf16x8 (&x)[NS]) {
+  if constexpr (NS == 3) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t[0], x[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t[2], x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t[1], x[1], acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t[0], x[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t[1], x[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t[0], x[0], acc, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -101,17 +120,18 @@ __device__ __forceinline__ void mma3(f32x16& acc, const bf16x8& th, const bf16x8
 // registers and walks a strided list of items, the next item's spectrum columns in flight during the products.  Before, a
 // workgroup fetched a k step's fragments from L2 one step ahead of their use — eight dependent round trips that made up most of
 // its 20 us life, and 1280 such workgroups met 1024 resident slots at B = 256.
-template <bool ADJ>
-__global__ __launch_bounds__(256, 2) void synth_mfma_kernel(const float* __restrict__ spec, float* __restrict__ wave,
-                                                            const __bf16* __restrict__ tab, int B, int nitems) {
-  __shared__ __attribute__((aligned(16))) char smem[FT * LDF * 4 + (ADJ ? SLOTS * HOP * 4 : 0)];
-  __bf16* Xs = reinterpret_cast<__bf16*>(smem);               // [re|im][hi|lo][128 k][32 f] bf16 = 32 KB
+template <bool ADJ, int NS>
+__global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void synth_mfma_kernel(const float* __restrict__ spec, float* __restrict__ wave,
+                                                                          const __bf16* __restrict__ tab, int B, int nitems) {
+  constexpr int IMG = FT * LDF * 4 > 2 * NS * NBIN * FT * 2 ? FT * LDF * 4 : 2 * NS * NBIN * FT * 2;
+  __shared__ __attribute__((aligned(16))) char smem[IMG + (ADJ ? SLOTS * HOP * 4 : 0)];
+  __bf16* Xs = reinterpret_cast<__bf16*>(smem);               // [re|im][term][128 k][32 f] bf16 = 32 KB (NS = 2)
   float* Fs = reinterpret_cast<float*>(smem);                 // [32 f][257] floats, after the products (aliases Xs)
-  float* Ob = reinterpret_cast<float*>(smem + FT * LDF * 4);  // ADJ: this item's padded-domain sums
+  float* Ob = reinterpret_cast<float*>(smem + IMG);           // ADJ: this item's padded-domain sums
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  TabFrags tb[8];
+  TabFrags<NS> tb[8];                                         // NS = 3: 192 registers, one workgroup per CU
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) tb[ks] = load_tab(tab, w, ks, lane);
+  for (int ks = 0; ks < 8; ++ks) tb[ks] = load_tab<NS>(tab, w, ks, lane);
   // Blocks are dealt round-robin to the 8 XCDs.  The 32-frame windows of a tile's five items start at frame 28 j - 4: their
   // 128-byte row segments straddle two cache lines each, and on five different L2s every line was fetched from HBM twice
   // (PMC: 2.04 x the spectrum).  Item id -> (tile, group) so that the groups of one tile share an XCD (the grid is a multiple of
@@ -146,12 +166,17 @@ __global__ __launch_bounds__(256, 2) void synth_mfma_kernel(const float* __restr
       const int id = tid + 256 * q, row = id >> 3, k = row & (NBIN - 1), c4 = 4 * (id & 7);
       const float sc = ADJ ? 1.0f : (k == 0 ? 1.0f : 2.0f) / (float)NFFT;
       const float e[4] = {v[q].x * sc, v[q].y * sc, v[q].z * sc, v[q].w * sc};
-      bf16x4 hi, lo;
+      bf16x4 pt[NS];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { __bf16 h_, l_; split_bf16(e[u], h_, l_); hi[u] = h_; lo[u] = l_; }
-      __bf16* dst = Xs + ((row >> 7) * 2) * (NBIN * FT) + k * FT + c4;
-      *reinterpret_cast<bf16x4*>(dst) = hi;
-      *reinterpret_cast<bf16x4*>(dst + NBIN * FT) = lo;
+      for (int u = 0; u < 4; ++u) {
+        __bf16 t_[NS];
+        split_terms<NS>(e[u], t_);
+#pragma unroll
+        for (int z = 0; z < NS; ++z) pt[z][u] = t_[z];
+      }
+      __bf16* dst = Xs + ((row >> 7) * NS) * (NBIN * FT) + k * FT + c4;
+#pragma unroll
+      for (int z = 0; z < NS; ++z) *reinterpret_cast<bf16x4*>(dst + z * NBIN * FT) = pt[z];
     }
     __syncthreads();
     if (item + (int)gridDim.x < nitems) fetch(item + gridDim.x);   // next item: in flight during the products and the overlap-add
@@ -162,10 +187,14 @@ __global__ __launch_bounds__(256, 2) void synth_mfma_kernel(const float* __restr
     for (int e = 0; e < 16; ++e) { E[e] = 0.f; O[e] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const bf16x8 rh = tr_frag32(Xs + 0 * NBIN * FT, ks, lane), rl = tr_frag32(Xs + 1 * NBIN * FT, ks, lane);
-      const bf16x8 ih = tr_frag32(Xs + 2 * NBIN * FT, ks, lane), il = tr_frag32(Xs + 3 * NBIN * FT, ks, lane);
-      mma3(E, tb[ks].ch, tb[ks].cl, rh, rl);
-      mma3(O, tb[ks].sh, tb[ks].sl, ih, il);
+      bf16x8 re[NS], im[NS];
+#pragma unroll
+      for (int z = 0; z < NS; ++z) {
+        re[z] = tr_frag32(Xs + z * NBIN * FT, ks, lane);
+        im[z] = tr_frag32(Xs + (NS + z) * NBIN * FT, ks, lane);
+      }
+      mma_split<NS>(E, tb[ks].c, re);
+      mma_split<NS>(O, tb[ks].s, im);
     }
     __syncthreads();                                          // every wave is done with Xs: the frame image takes its place
     {
@@ -220,15 +249,16 @@ __global__ __launch_bounds__(256, 2) void synth_mfma_kernel(const float* __restr
 // ADJ = true  : dspec = istft^T(dwave)     zero padding, 1 / envelope on the samples, (1 | 2) / 255 on the bins
 // Work item = 32 frames x 128 bins x (re, im) of one tile (four per tile); wave w owns bins [32 w, 32 w + 32).  Persistent
 // workgroups with the table fragments in registers and the next item's samples in flight, as in synth_mfma_kernel.
-template <bool ADJ>
-__global__ __launch_bounds__(256, 2) void analysis_mfma_kernel(const float* __restrict__ wave, float* __restrict__ spec,
-                                                               const __bf16* __restrict__ tab, int nitems) {
-  __shared__ __attribute__((aligned(16))) float xs[2][SPAN + 8];             // this item's samples | the next item's
-  __shared__ __attribute__((aligned(16))) __bf16 UV[4 * FT * LDU];          // [u|v][hi|lo][32 t][136]
+template <bool ADJ, int NS>
+__global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void analysis_mfma_kernel(const float* __restrict__ wave, float* __restrict__ spec,
+                                                                             const __bf16* __restrict__ tab, int nitems) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];                 // analysis_smem(NS) bytes (70 KB with three terms)
+  float (*xs)[SPAN + 8] = reinterpret_cast<float (*)[SPAN + 8]>(dsm);        // [2]: this item's samples | the next item's
+  __bf16* UV = reinterpret_cast<__bf16*>(dsm + 2 * (SPAN + 8) * 4);          // [u|v][term][32 t][136]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  TabFrags tb[8];
+  TabFrags<NS> tb[8];
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) tb[ks] = load_tab(tab, w, ks, lane);
+  for (int ks = 0; ks < 8; ++ks) tb[ks] = load_tab<NS>(tab, w, ks, lane);
   constexpr int NPV = (SPAN + 255) / 256;                      // 9 samples per thread
   float pv[NPV];
   auto fetch = [&](int item) {
@@ -289,19 +319,24 @@ __global__ __launch_bounds__(256, 2) void analysis_mfma_kernel(const float* __re
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int n0 = 8 * (c0 + 8 * it);
-        bf16x8 uh, ul, vh, vl;
+        bf16x8 ut[NS], vt[NS];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const bool dc = n0 + j == 0;
-          __bf16 h_, l_;
-          split_bf16(dc ? a[it][j] : a[it][j] + m[it][j], h_, l_); uh[j] = h_; ul[j] = l_;
-          split_bf16(dc ? 0.f : a[it][j] - m[it][j], h_, l_); vh[j] = h_; vl[j] = l_;
+          __bf16 t_[NS];
+          split_terms<NS>(dc ? a[it][j] : a[it][j] + m[it][j], t_);
+#pragma unroll
+          for (int z = 0; z < NS; ++z) ut[z][j] = t_[z];
+          split_terms<NS>(dc ? 0.f : a[it][j] - m[it][j], t_);
+#pragma unroll
+          for (int z = 0; z < NS; ++z) vt[z][j] = t_[z];
         }
         __bf16* d = UV + t * LDU + n0;
-        *reinterpret_cast<bf16x8*>(d) = uh;
-        *reinterpret_cast<bf16x8*>(d + FT * LDU) = ul;
-        *reinterpret_cast<bf16x8*>(d + 2 * FT * LDU) = vh;
-        *reinterpret_cast<bf16x8*>(d + 3 * FT * LDU) = vl;
+#pragma unroll
+        for (int z = 0; z < NS; ++z) {
+          *reinterpret_cast<bf16x8*>(d + z * FT * LDU) = ut[z];
+          *reinterpret_cast<bf16x8*>(d + (NS + z) * FT * LDU) = vt[z];
+        }
       }
     }
     __syncthreads();
@@ -312,12 +347,14 @@ __global__ __launch_bounds__(256, 2) void analysis_mfma_kernel(const float* __re
     const __bf16* brow = UV + r * LDU + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const bf16x8 uh = *reinterpret_cast<const bf16x8*>(brow + 16 * ks);
-      const bf16x8 ul = *reinterpret_cast<const bf16x8*>(brow + 16 * ks + FT * LDU);
-      const bf16x8 vh = *reinterpret_cast<const bf16x8*>(brow + 16 * ks + 2 * FT * LDU);
-      const bf16x8 vl = *reinterpret_cast<const bf16x8*>(brow + 16 * ks + 3 * FT * LDU);
-      mma3(RE, tb[ks].ch, tb[ks].cl, uh, ul);
-      mma3(IM, tb[ks].sh, tb[ks].sl, vh, vl);
+      bf16x8 ut[NS], vt[NS];
+#pragma unroll
+      for (int z = 0; z < NS; ++z) {
+        ut[z] = *reinterpret_cast<const bf16x8*>(brow + 16 * ks + z * FT * LDU);
+        vt[z] = *reinterpret_cast<const bf16x8*>(brow + 16 * ks + (NS + z) * FT * LDU);
+      }
+      mma_split<NS>(RE, tb[ks].c, ut);
+      mma_split<NS>(IM, tb[ks].s, vt);
     }
     if (more) stage(xs[cur ^ 1]);                             // (the other buffer: its reader, the previous fold, is long done)
     float* dst = spec + (int64_t)b * 2 * NBIN * NFRAME + t0 + r;
@@ -331,55 +368,74 @@ __global__ __launch_bounds__(256, 2) void analysis_mfma_kernel(const float* __re
   }
 }
 
-// persistent grids: two 256-thread workgroups per CU (tables in registers: 2 waves per SIMD), a multiple of 8 (XCD affinity)
-inline int persistent_grid(int nitems) {
-  int g = nitems < 512 ? nitems : 512;
+// persistent grids: two 256-thread workgroups per CU (tables in registers: 2 waves per SIMD; one with three terms), a multiple of
+// 8 (XCD affinity)
+inline int persistent_grid(int nitems, int terms) {
+  const int cap = terms == 2 ? 512 : 256;
+  int g = nitems < cap ? nitems : cap;
   return (g + 7) / 8 * 8;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+constexpr int analysis_smem(int NS) { return 2 * (SPAN + 8) * 4 + 2 * NS * FT * LDU * 2; }
+
+template <bool ADJ, int NS>
+int launch_synth(const float* in, float* out, const void* tables, int B, hipStream_t st) {
+  const int nitems = 8 * ((B + 7) / 8) * SYN_GROUPS;
+  hipLaunchKernelGGL((synth_mfma_kernel<ADJ, NS>), dim3(persistent_grid(nitems, NS)), dim3(256), 0, st, in, out,
+                     static_cast<const __bf16*>(tables), B, nitems);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+template <bool ADJ, int NS>
+int launch_analysis(const float* in, float* out, const void* tables, int B, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(analysis_mfma_kernel<ADJ, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              analysis_smem(NS));
+    attr = true;
+  }
+  const int nitems = (NFRAME / FT) * B;
+  hipLaunchKernelGGL((analysis_mfma_kernel<ADJ, NS>), dim3(persistent_grid(nitems, NS)), dim3(256), analysis_smem(NS), st, in, out,
+                     static_cast<const __bf16*>(tables), nitems);
+  WM_CHECK_LAUNCH();
+  return WM_OK;
+}
+
 }  // namespace
 
-extern "C" int64_t wm_stft255_table_bytes(void) { return (int64_t)TAB_ELEMS * 2; }
+// terms: 2 (hi + lo operands: the bf16 compute mode) or 3 (hi + mid + lo: fp32-grade, the fp32 / split modes); the tables buffer
+// must have been filled with the same value
+extern "C" int64_t wm_stft255_table_bytes(int32_t terms) { return terms == 2 || terms == 3 ? (int64_t)tab_elems(terms) * 2 : 0; }
 
-extern "C" int wm_stft255_tables(void* tables, void* stream) {
-  if (!tables || !aligned16(tables)) return WM_EINVAL;
-  hipLaunchKernelGGL(stft_table_kernel, dim3(4 * 8 * 64 * 8 / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<__bf16*>(tables));
+extern "C" int wm_stft255_tables(void* tables, int32_t terms, void* stream) {
+  if (!tables || !aligned16(tables) || (terms != 2 && terms != 3)) return WM_EINVAL;
+  if (terms == 2)
+    hipLaunchKernelGGL(stft_table_kernel<2>, dim3(TAB_PLANE / 256), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<__bf16*>(tables));
+  else
+    hipLaunchKernelGGL(stft_table_kernel<3>, dim3(TAB_PLANE / 256), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<__bf16*>(tables));
   WM_CHECK_LAUNCH();
   return WM_OK;
 }
 
-extern "C" int wm_istft255_fwd(const float* spec, float* wave, const void* tables, int32_t B, void* stream) {
-  if (!spec || !wave || !tables || B <= 0 || !aligned16(spec) || !aligned16(tables)) return WM_EINVAL;
-  const int nitems = 8 * ((B + 7) / 8) * SYN_GROUPS;
-  hipLaunchKernelGGL(synth_mfma_kernel<false>, dim3(persistent_grid(nitems)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     spec, wave, static_cast<const __bf16*>(tables), B, nitems);
-  WM_CHECK_LAUNCH();
-  return WM_OK;
+extern "C" int wm_istft255_fwd(const float* spec, float* wave, const void* tables, int32_t terms, int32_t B, void* stream) {
+  if (!spec || !wave || !tables || B <= 0 || !aligned16(spec) || !aligned16(tables) || (terms != 2 && terms != 3)) return WM_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return terms == 2 ? launch_synth<false, 2>(spec, wave, tables, B, st) : launch_synth<false, 3>(spec, wave, tables, B, st);
 }
-extern "C" int wm_stft255_bwd(const float* dspec, float* dwave, const void* tables, int32_t B, void* stream) {
-  if (!dspec || !dwave || !tables || B <= 0 || !aligned16(dspec) || !aligned16(tables)) return WM_EINVAL;
-  const int nitems = 8 * ((B + 7) / 8) * SYN_GROUPS;
-  hipLaunchKernelGGL(synth_mfma_kernel<true>, dim3(persistent_grid(nitems)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     dspec, dwave, static_cast<const __bf16*>(tables), B, nitems);
-  WM_CHECK_LAUNCH();
-  return WM_OK;
+extern "C" int wm_stft255_bwd(const float* dspec, float* dwave, const void* tables, int32_t terms, int32_t B, void* stream) {
+  if (!dspec || !dwave || !tables || B <= 0 || !aligned16(dspec) || !aligned16(tables) || (terms != 2 && terms != 3)) return WM_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return terms == 2 ? launch_synth<true, 2>(dspec, dwave, tables, B, st) : launch_synth<true, 3>(dspec, dwave, tables, B, st);
 }
-extern "C" int wm_stft255_fwd(const float* wave, float* spec, const void* tables, int32_t B, void* stream) {
-  if (!wave || !spec || !tables || B <= 0 || !aligned16(tables)) return WM_EINVAL;
-  const int nitems = (NFRAME / FT) * B;
-  hipLaunchKernelGGL(analysis_mfma_kernel<false>, dim3(persistent_grid(nitems)), dim3(256), 0, static_cast<hipStream_t>(stream), wave,
-                     spec, static_cast<const __bf16*>(tables), nitems);
-  WM_CHECK_LAUNCH();
-  return WM_OK;
+extern "C" int wm_stft255_fwd(const float* wave, float* spec, const void* tables, int32_t terms, int32_t B, void* stream) {
+  if (!wave || !spec || !tables || B <= 0 || !aligned16(tables) || (terms != 2 && terms != 3)) return WM_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return terms == 2 ? launch_analysis<false, 2>(wave, spec, tables, B, st) : launch_analysis<false, 3>(wave, spec, tables, B, st);
 }
-extern "C" int wm_istft255_bwd(const float* dwave, float* dspec, const void* tables, int32_t B, void* stream) {
-  if (!dwave || !dspec || !tables || B <= 0 || !aligned16(tables)) return WM_EINVAL;
-  const int nitems = (NFRAME / FT) * B;
-  hipLaunchKernelGGL(analysis_mfma_kernel<true>, dim3(persistent_grid(nitems)), dim3(256), 0, static_cast<hipStream_t>(stream), dwave,
-                     dspec, static_cast<const __bf16*>(tables), nitems);
-  WM_CHECK_LAUNCH();
-  return WM_OK;
+extern "C" int wm_istft255_bwd(const float* dwave, float* dspec, const void* tables, int32_t terms, int32_t B, void* stream) {
+  if (!dwave || !dspec || !tables || B <= 0 || !aligned16(tables) || (terms != 2 && terms != 3)) return WM_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return terms == 2 ? launch_analysis<true, 2>(dwave, dspec, tables, B, st) : launch_analysis<true, 3>(dwave, dspec, tables, B, st);
 }

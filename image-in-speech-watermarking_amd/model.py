@@ -360,13 +360,18 @@ class UformerAudio(nn.Module):
         if self._tjobs is None or self._tjobs[0].device != self._flat.device:
             rows, tile0 = [], 0
             for name, shape, _ in self._specs:
-                if len(shape) == 2 and name.endswith(("attn.qkv.to_q.weight", "attn.proj.weight", "mlp.linear1.0.weight",
-                                                      "mlp.linear2.0.weight")) and min(shape) >= self.BIG_C:
+                if len(shape) != 2:
+                    continue
+                big = name.endswith(("attn.qkv.to_q.weight", "attn.proj.weight", "mlp.linear1.0.weight",
+                                     "mlp.linear2.0.weight")) and min(shape) >= self.BIG_C
+                # Wqkv^T of the blocks whose attention half runs as one launch (csrc/attn_fused.hip: C <= 128)
+                small = name.endswith("attn.qkv.to_q.weight") and shape[0] <= 128
+                if big or small:
                     n, k = shape
                     if name.endswith("to_q.weight"):
                         n = 3 * n                                 # the fused [3C, C] q | kv operand (adjacent in the arena)
                     rows.append((self._offsets[name], n, k, tile0))
-                    tile0 += (n // 64) * (k // 64)
+                    tile0 += ((n + 63) // 64) * ((k + 63) // 64)
             self._tjobs = (torch.tensor(rows, dtype=torch.int32, device=self._flat.device).contiguous(), len(rows), tile0)
         return self._tjobs
 
@@ -402,6 +407,15 @@ class UformerAudio(nn.Module):
             return None                                            # (no copy: the product reads the weight as it lies)
         off = (v.data_ptr() - self._flat.data_ptr()) // 4
         return self._flat_ht[off:off + v.numel()].view(v.shape[1], v.shape[0])
+
+    def _WqkvT(self, pre):
+        """[C, 3C] bf16 transpose of a block's fused q | k | v weight from the per-step batched copy (operand of wm_attn_half_bwd)."""
+        v = self._views[pre + "attn.qkv.to_q.weight"]
+        C = v.shape[0]
+        if self.compute_mode != "bf16" or self._flat_ht is None:
+            return None
+        off = (v.data_ptr() - self._flat.data_ptr()) // 4
+        return self._flat_ht[off:off + 3 * C * C].view(C, 3 * C)
 
     def _ensure_runtime(self, device):
         if self._anchor is None or self._anchor.device != device:
@@ -569,8 +583,10 @@ class UformerAudio(nn.Module):
         if half and ops.attn_half_fusable(hw, C):
             # C <= 128: norm2' -> projection dX -> window-attention backward -> q | k | v dX -> norm1' as ONE window-local launch
             # (csrc/attn_fused.hip); the two weight-gradient products read the bf16 tensors it writes (dx1h carries s1)
-            wqT = H(dev, C, 3 * C)
-            ops.strided3(P[pre + "attn.qkv.w"], wqT, (C, 3 * C, 1), (1, C, 0), (3 * C, 1, 0))
+            wqT = self._WqkvT(pre)
+            if wqT is None:                                        # (no batched copy this step: make the one operand here)
+                wqT = H(dev, C, 3 * C)
+                ops.strided3(P[pre + "attn.qkv.w"], wqT, (C, 3 * C, 1), (1, C, 0), (3 * C, 1, 0))
             dx1h, dqkv, dx, dxh = H(dev, M, C), H(dev, M, 3 * C), _E(dev, M, C), H(dev, M, C)
             ops.attn_half_bwd(dxn2, dy, x1, mean2, rstd2, P[pre + "norm2.weight"], x, mean1, rstd1, P[pre + "norm1.weight"], qkv, o, lse,
                               P[pre + "attn.relative_position_bias_table"], W(pre + "attn.proj.weight"), wqT, dx1h, dqkv, dx,
@@ -852,7 +868,11 @@ class UformerAudio(nn.Module):
         if embed_only:
             return (yw, wm_pred), None
         wave = _E(dev, B, WAVE_LEN)
-        ops.istft_fwd(yw, wave, B)
+        # the waveform round trip at fp32 grade outside bf16 mode (three-term transforms, scalar fp32 low-pass passes): the
+        # fp32 / split outputs are held to 1e-4 of the CPU oracle BEHIND the extractor
+        precise = self.compute_mode != "bf16"
+        terms = 3 if precise else 2
+        ops.istft_fwd(yw, wave, B, terms)
         att = attack if (attack is not None and attack.flags) else None
         step_used = None
         if att is not None:
@@ -860,11 +880,11 @@ class UformerAudio(nn.Module):
             # forward before this pass's backward advances the live counter)
             step_used = torch.empty_like(self._step_t)
             ops.step_copy(self._step_t, step_used)
-            wave_a, sigma = attack_forward(att, wave, step_used)
+            wave_a, sigma = attack_forward(att, wave, step_used, precise=precise)
         else:
             wave_a, sigma = wave, None
         spec = _E(dev, B, 2, 128, 128)
-        ops.stft_fwd(wave_a, spec, B)
+        ops.stft_fwd(wave_a, spec, B, terms)
         S["stft"] = (att, wave, sigma, step_used)
         c1 = ops.conv_desc(B, 2, 128, 128, 4, (3, 3), (1, 1), (1, 1), act="relu")
         mid = _E(dev, B, 4, 128, 128)
@@ -907,11 +927,13 @@ class UformerAudio(nn.Module):
             ops.axpbyz(dspec, 1.0, dspec, 1.0, d_src, dspec.numel())
         att, wave, sigma, step_used = S["stft"]
         dwave = _E(dev, B, WAVE_LEN)
-        ops.stft_bwd(dspec, dwave, B)
+        precise = self.compute_mode != "bf16"
+        terms = 3 if precise else 2
+        ops.stft_bwd(dspec, dwave, B, terms)
         if att is not None:
-            dwave = attack_backward(att, wave, dwave, sigma, step_used)
+            dwave = attack_backward(att, wave, dwave, sigma, step_used, precise=precise)
         dy = _E(dev, B, 2, 128, 128)
-        ops.istft_bwd(dwave, dy, B)
+        ops.istft_bwd(dwave, dy, B, terms)
         if S["extract_from"] == "y":
             ops.axpbyz(dy, 1.0, dy, 1.0, d_src, dy.numel())
         # y = x + noise

@@ -375,35 +375,40 @@ def wave_attack(wave, snr_db=None, amp=None, echo=None, jitter=None, requantize=
 _stft_tabs = {}
 
 
-def stft_tables(device):
-    """The folded cos / sin DFT matrices (bf16 hi + lo, MFMA operand order) of the n_fft = 255 transforms: one 128 KB
-    device buffer per GPU, filled once by wm_stft255_tables (outside any graph capture: the first, eager, call makes it)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+def stft_tables(device, terms=2):
+    """The folded cos / sin DFT matrices (`terms` bf16 planes each, MFMA operand order) of the n_fft = 255 transforms: one
+    128 KB (terms = 2) / 192 KB (terms = 3) device buffer per GPU and precision, filled once by wm_stft255_tables (outside any
+    graph capture: the first, eager, call makes it)."""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (idx, int(terms))
     t = _stft_tabs.get(key)
     if t is None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("stft_tables: first use inside a graph capture; run one eager step (or ops.stft_tables) first")
-        t = torch.empty(int(lib.wm_stft255_table_bytes()) // 2, device=torch.device("cuda", key), dtype=torch.bfloat16)
-        check(lib.wm_stft255_tables(ptr(t), _stream()), "wm_stft255_tables")
+        nbytes = int(lib.wm_stft255_table_bytes(int(terms)))
+        if nbytes <= 0:
+            raise ValueError("stft_tables: terms is 2 (bf16 compute mode) or 3 (fp32 / split modes)")
+        t = torch.empty(nbytes // 2, device=torch.device("cuda", idx), dtype=torch.bfloat16)
+        check(lib.wm_stft255_tables(ptr(t), int(terms), _stream()), "wm_stft255_tables")
         torch.cuda.current_stream().synchronize()              # other streams may use it next
         _stft_tabs[key] = t
     return t
 
 
-def istft_fwd(spec, wave, B):
-    check(lib.wm_istft255_fwd(ptr(spec), ptr(wave), ptr(stft_tables(wave.device)), B, _stream()), "wm_istft255_fwd")
+def istft_fwd(spec, wave, B, terms=2):
+    check(lib.wm_istft255_fwd(ptr(spec), ptr(wave), ptr(stft_tables(wave.device, terms)), terms, B, _stream()), "wm_istft255_fwd")
 
 
-def stft_fwd(wave, spec, B):
-    check(lib.wm_stft255_fwd(ptr(wave), ptr(spec), ptr(stft_tables(spec.device)), B, _stream()), "wm_stft255_fwd")
+def stft_fwd(wave, spec, B, terms=2):
+    check(lib.wm_stft255_fwd(ptr(wave), ptr(spec), ptr(stft_tables(spec.device, terms)), terms, B, _stream()), "wm_stft255_fwd")
 
 
-def istft_bwd(dwave, dspec, B):
-    check(lib.wm_istft255_bwd(ptr(dwave), ptr(dspec), ptr(stft_tables(dspec.device)), B, _stream()), "wm_istft255_bwd")
+def istft_bwd(dwave, dspec, B, terms=2):
+    check(lib.wm_istft255_bwd(ptr(dwave), ptr(dspec), ptr(stft_tables(dspec.device, terms)), terms, B, _stream()), "wm_istft255_bwd")
 
 
-def stft_bwd(dspec, dwave, B):
-    check(lib.wm_stft255_bwd(ptr(dspec), ptr(dwave), ptr(stft_tables(dwave.device)), B, _stream()), "wm_stft255_bwd")
+def stft_bwd(dspec, dwave, B, terms=2):
+    check(lib.wm_stft255_bwd(ptr(dspec), ptr(dwave), ptr(stft_tables(dwave.device, terms)), terms, B, _stream()), "wm_stft255_bwd")
 
 
 def attack_fwd(desc, wave, out, sigma, B, L):

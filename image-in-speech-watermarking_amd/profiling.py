@@ -60,10 +60,10 @@ COST = {
     "pixel_unshuffle": lambda ds, dy4, *a: (0.0, 8.0 * dy4.numel()),
     "copy_cols": lambda src, lds, s0, dst, ldd, c0, rows, C, accumulate=False: (0.0, 8.0 * rows * C),
     "axpbyz": lambda out, a, x, b, y, n: (2.0 * n, 12.0 * n),
-    "istft_fwd": lambda s, w, B: (2.0 * 10.2e6 * B, B * (131072.0 + 32008.0)),
-    "stft_fwd": lambda w, s, B: (2.0 * 8.4e6 * B, B * (131072.0 + 32008.0)),
-    "istft_bwd": lambda w, s, B: (2.0 * 8.4e6 * B, B * (131072.0 + 32008.0)),
-    "stft_bwd": lambda s, w, B: (2.0 * 10.2e6 * B, B * (131072.0 + 32008.0)),
+    "istft_fwd": lambda s, w, B, terms=2: (2.0 * 10.2e6 * B, B * (131072.0 + 32008.0)),
+    "stft_fwd": lambda w, s, B, terms=2: (2.0 * 8.4e6 * B, B * (131072.0 + 32008.0)),
+    "istft_bwd": lambda w, s, B, terms=2: (2.0 * 8.4e6 * B, B * (131072.0 + 32008.0)),
+    "stft_bwd": lambda s, w, B, terms=2: (2.0 * 10.2e6 * B, B * (131072.0 + 32008.0)),
     "attack_fwd": lambda d, w, o, s, B, L: (0.0, 8.0 * B * L),
     "attack_bwd": lambda d, w, do, s, dw, B, L: (0.0, 12.0 * B * L),
     "adamw": lambda p, g, m, v, n, *a: (12.0 * n, 28.0 * n),

@@ -206,8 +206,9 @@ int wm_minmax(const float* x, int64_t n, float* out_min_max, float* scratch, voi
 int wm_range_map(const float* x, float* out, const float* min_max, float lo, float hi, int32_t inverse, int64_t n, void* stream);
 /* transposed bf16 copies of many [rows, cols] fp32 matrices of the parameter arena in one launch: the dX GEMMs of the
  * 256 x 256 tile kernel (csrc/gemm_big.hip) take their weight K-contiguous, i.e. W^T of nn.Linear's [out, in] weight
- * (model.py:460-471,549,700,711).  jobs (device, int32 x 4 per job, 16-byte aligned): {element offset of the matrix in BOTH
- * arenas, rows, cols, index of the job's first 64 x 64 tile}; rows and cols are multiples of 64, offsets of 8. */
+ * (model.py:460-471,549,700,711), and wm_attn_half_bwd takes Wqkv^T.  jobs (device, int32 x 4 per job, 16-byte aligned):
+ * {element offset of the matrix in BOTH arenas, rows, cols, index of the job's first 64 x 64 tile}; a job has
+ * ceil(rows / 64) * ceil(cols / 64) tiles; rows and cols are multiples of 4, offsets of 8. */
 int wm_transpose_cast_jobs(const float* arena, void* arena_t_bf16, const int32_t* jobs, int32_t njobs, int32_t total_tiles,
                            void* stream);
 
@@ -280,15 +281,19 @@ int wm_sinc_resample(const float* in, int64_t Lin, int32_t U, double ratio, cons
 
 /* ---- in-graph STFT round trip — torch.istft / torch.stft with n_fft=255, hop 63, rectangular
  * window, center/reflect (model.py:2458,2463).  spec: [B,2,128,128] (re|im planes), wave: [B,8002] */
-/* `tables`: wm_stft255_table_bytes() bytes of caller-owned device memory (16-byte aligned) filled ONCE by
- * wm_stft255_tables(): the folded cos / sin DFT matrices in bf16 hi + lo halves, in MFMA operand order.  The transforms
- * run as split-precision bf16 MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate: ~2e-6 of full scale).           */
-int64_t wm_stft255_table_bytes(void);
-int wm_stft255_tables(void* tables, void* stream);
-int wm_istft255_fwd(const float* spec, float* wave, const void* tables, int32_t B, void* stream);
-int wm_stft255_fwd(const float* wave, float* spec, const void* tables, int32_t B, void* stream);
-int wm_istft255_bwd(const float* dwave, float* dspec, const void* tables, int32_t B, void* stream);
-int wm_stft255_bwd(const float* dspec, float* dwave, const void* tables, int32_t B, void* stream);
+/* `tables`: wm_stft255_table_bytes(terms) bytes of caller-owned device memory (16-byte aligned) filled ONCE by
+ * wm_stft255_tables(terms): the folded cos / sin DFT matrices as `terms` bf16 planes each, in MFMA operand order.  The
+ * transforms run as split-precision bf16 MFMA products with fp32 accumulation:
+ *   terms = 2  hi + lo operands, hi*hi + hi*lo + lo*hi: ~2e-6 of full scale (the bf16 compute mode);
+ *   terms = 3  hi + mid + lo operands, six products: fp32-grade (~1e-7), the fp32 / split compute modes, whose outputs behind
+ *              the extractor are held to 1e-4 of the CPU oracle.
+ * `terms` of a transform call must be the value its tables were filled with; anything else than 2 or 3: WM_EINVAL.        */
+int64_t wm_stft255_table_bytes(int32_t terms);
+int wm_stft255_tables(void* tables, int32_t terms, void* stream);
+int wm_istft255_fwd(const float* spec, float* wave, const void* tables, int32_t terms, int32_t B, void* stream);
+int wm_stft255_fwd(const float* wave, float* spec, const void* tables, int32_t terms, int32_t B, void* stream);
+int wm_istft255_bwd(const float* dwave, float* dspec, const void* tables, int32_t terms, int32_t B, void* stream);
+int wm_stft255_bwd(const float* dspec, float* dwave, const void* tables, int32_t terms, int32_t B, void* stream);
 
 /* ---- waveform attacks (audio_attack.py:21-30,55-58,71-83,99-125; torch awgn model.py:15-41).
  * One workgroup per waveform keeps the row in LDS through the whole chain.

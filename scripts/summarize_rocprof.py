@@ -95,7 +95,7 @@ def family(name):
     name = re.sub(r"\(anonymous namespace\)::", "", re.sub(r"^void ", "", name))
     base = re.split(r"[<(]", name)[0]
     if base in PER_INSTANCE:
-        b = re.search(r"<\s*(true|false|\(bool\)[01]|[01])\s*>", name)
+        b = re.search(r"<\s*(true|false|\(bool\)[01]|[01])\s*[,>]", name)   # (<ADJ> or <ADJ, terms>)
         flag = b.group(1) if b else "false"
         return f"{base}<{'true' if flag in ('true', '1', '(bool)1') else 'false'}>"
     return base

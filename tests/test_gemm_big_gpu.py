@@ -146,6 +146,27 @@ def test_transpose_cast_jobs(wm):
     assert bool((dst[:o1] == 0).all()) and bool((dst[o1 + 768 * 256:o2] == 0).all())
 
 
+def test_transpose_cast_jobs_partial_tiles(wm):
+    """The q | k | v weights of the C <= 128 blocks ([96, 32], [192, 64], [384, 128]) in the same launch as a wide one: edge tiles of
+    a 64 x 64 grid are partial, nothing outside a matrix is written."""
+    ops = wm.ops
+    shapes = [(96, 32), (768, 256), (192, 64), (384, 128), (100, 36)]
+    offs, jobs, off, tile0 = [], [], 8, 0
+    for r, c in shapes:
+        offs.append(off)
+        jobs.append([off, r, c, tile0])
+        tile0 += ((r + 63) // 64) * ((c + 63) // 64)
+        off += r * c + 8
+    arena = rnd("tcjp", (off,), 1.0, torch.float32)
+    dst = torch.zeros(off, device="cuda", dtype=BF)
+    ops.transpose_cast_jobs(arena, dst, torch.tensor(jobs, dtype=torch.int32, device="cuda"), len(jobs), tile0)
+    mask = torch.ones(off, dtype=torch.bool, device="cuda")
+    for (r, c), o in zip(shapes, offs):
+        assert torch.equal(dst[o:o + r * c].view(c, r), arena[o:o + r * c].view(r, c).t().to(BF)), (r, c)
+        mask[o:o + r * c] = False
+    assert bool((dst[mask] == 0).all())
+
+
 # (tokens, N_out, K_in): weight-gradient launches of the B = 256 step that the dispatcher hands to gemm_tn_big_kernel
 TN_BIG = [
     (65536, 1024, 256, "fc1 C=256 trunk: 4 tiles x 64 token ranges"),

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(wm):
     nm = subprocess.run(["nm", "-D", "--defined-only", wm.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (wm_[a-z0-9_]+)", nm))
     assert declared <= exported
-    assert wm.lib.wm_abi_version() == 6
+    assert wm.lib.wm_abi_version() == 7
 
 
 def test_model_surface_matches_reference(wm):

@@ -415,7 +415,10 @@ def test_maxpool(wm, planes, H, W, kh, kw):
 
 
 # ------------------------------------------------------------------------------- STFT round trip
-def test_stft_istft_fwd_bwd(wm, golden):
+@pytest.mark.parametrize("terms", [2, 3])
+def test_stft_istft_fwd_bwd(wm, golden, terms):
+    """terms = 2: hi + lo operands (bf16 compute mode); 3: hi + mid + lo (fp32 / split modes), same bounds against the fp32 oracle
+    here — test_stft_three_terms_are_fp32_grade holds the tighter one against float64."""
     ops = wm.ops
     B = 3
     spec = synth_array("sspec", (B, 2, 128, 128)).requires_grad_()
@@ -423,31 +426,74 @@ def test_stft_istft_fwd_bwd(wm, golden):
     gw = synth_array("sgw", (B, 8002))
     wave_ref.backward(gw)
     wave = torch.empty(B, 8002, device="cuda")
-    ops.istft_fwd(dev(spec.detach()), wave, B)
+    ops.istft_fwd(dev(spec.detach()), wave, B, terms)
     assert_close(wave, wave_ref.detach(), 1e-4, "istft fwd")
     dspec = torch.empty(B, 2, 128, 128, device="cuda")
-    ops.istft_bwd(dev(gw), dspec, B)
+    ops.istft_bwd(dev(gw), dspec, B, terms)
     assert_close(dspec, spec.grad, 1e-4, "istft bwd")
     w = (0.2 * synth_array("sw", (B, 8002))).requires_grad_()
     s_ref = O.stft255(w)
     gs = synth_array("sgs", s_ref.shape)
     s_ref.backward(gs)
     s = torch.empty(B, 2, 128, 128, device="cuda")
-    ops.stft_fwd(dev(w.detach()), s, B)
+    ops.stft_fwd(dev(w.detach()), s, B, terms)
     assert_close(s, s_ref.detach(), 1e-4, "stft fwd")
     dw = torch.empty(B, 8002, device="cuda")
-    ops.stft_bwd(dev(gs), dw, B)
+    ops.stft_bwd(dev(gs), dw, B, terms)
     assert_close(dw, w.grad, 1e-4, "stft bwd")
     # golden produced by the reference's own torch.istft/torch.stft calls (model.py:2458,2463)
     g2 = golden("g2_stft")
     from synth import synth_tile
     y = synth_tile(2, "g2_y", 1.0)
     wv = torch.empty(2, 8002, device="cuda")
-    ops.istft_fwd(dev(y), wv, 2)
+    ops.istft_fwd(dev(y), wv, 2, terms)
     assert_close(wv, torch.from_numpy(g2["wave"]), 1e-4, "istft vs golden")
     sp = torch.empty(2, 2, 128, 128, device="cuda")
-    ops.stft_fwd(dev(torch.from_numpy(g2["wave"])), sp, 2)
+    ops.stft_fwd(dev(torch.from_numpy(g2["wave"])), sp, 2, terms)
     assert_close(sp, torch.from_numpy(g2["spec"]), 1e-4, "stft vs golden")
+
+
+def test_stft_three_terms_are_fp32_grade(wm):
+    """The fp32 / split compute modes' transforms (operands as three bf16 terms, six products) against float64 torch.stft / istft:
+    5e-7 of full scale where the two-term form measures 2e-6 .. 4e-6; adjoint identities at 1e-6 of the norms; a batch with several
+    items per persistent workgroup and padding items (B = 70 on 256 workgroups: 280 analysis items, 360 synthesis items of which 10
+    are padding), results bit-identical across launches."""
+    ops = wm.ops
+    B = 70
+    g = torch.Generator().manual_seed(5)
+    w = (0.2 * torch.randn(B, 8002, generator=g)).cuda()
+    sp = torch.randn(B, 2, 128, 128, generator=g).cuda()
+    win = torch.ones(255, dtype=torch.float64)
+    st = torch.view_as_real(torch.stft(w.double().cpu(), n_fft=255, window=win, return_complex=True)).permute(0, 3, 1, 2)
+    wv = torch.istft(torch.complex(sp[:, 0].double().cpu(), sp[:, 1].double().cpu()), n_fft=255, window=win)
+    outs = {}
+    for terms in (3, 2, 3):
+        s, x = torch.empty(B, 2, 128, 128, device="cuda"), torch.empty(B, 8002, device="cuda")
+        ds, dx = torch.empty(B, 2, 128, 128, device="cuda"), torch.empty(B, 8002, device="cuda")
+        ops.stft_fwd(w, s, B, terms)
+        ops.istft_fwd(sp, x, B, terms)
+        ops.istft_bwd(w, ds, B, terms)
+        ops.stft_bwd(sp, dx, B, terms)
+        if terms in outs:
+            for a, b_ in zip((s, x, ds, dx), outs[terms]):
+                assert torch.equal(a, b_)
+        outs[terms] = (s, x, ds, dx)
+    s3, x3, ds3, dx3 = outs[3]
+    s2, x2, _, _ = outs[2]
+
+    def err(a, ref):
+        return ((a.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    e3, e2 = (err(s3, st), err(x3, wv)), (err(s2, st), err(x2, wv))
+    assert max(e3) <= 5e-7, e3
+    assert max(e2) <= 1e-5 and min(e2) >= 2 * max(e3), (e2, e3)      # the two-term form is the coarser one, as documented
+    for b in (0, B // 2, B - 1):
+        assert err(s3[b], st[b]) <= 5e-7 and err(x3[b], wv[b]) <= 5e-7
+    lhs, rhs = (x3.double() * w.double()).sum().item(), (sp.double() * ds3.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * (x3.double().norm() * w.double().norm()).item(), (lhs, rhs)
+    lhs, rhs = (s3.double() * sp.double()).sum().item(), (w.double() * dx3.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * (s3.double().norm() * sp.double().norm()).item(), (lhs, rhs)
+    with pytest.raises(wm._lib.WmKernelError):
+        ops.check(wm.lib.wm_stft255_fwd(ops.ptr(w), ops.ptr(s3), ops.ptr(ops.stft_tables(w.device, 3)), 4, B, None), "wm_stft255_fwd")
 
 
 @pytest.mark.parametrize("B", [96, 131, 260])
