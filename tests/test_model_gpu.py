@@ -542,6 +542,9 @@ def test_config3_full_attack_stack_forward_and_gradients(wm, pmode):
         assert e <= 3e-3, (n, e)
 
 
+_C5_ORACLE = {}
+
+
 @pytest.mark.parametrize("pmode", PARITY_MODES)
 def test_config5_ten_tile_clips_quadrant_payload(wm, pmode):
     """BASELINE config 5 / row A14: 2 clips x 10 tiles (10 s at 16 kHz through the device data-prep STFT), a 64 x 64
@@ -564,20 +567,28 @@ def test_config5_ten_tile_clips_quadrant_payload(wm, pmode):
     cfg, attack = _full_attack_oracle(wm, m, B)
     loss, terms = O.train_losses(out, x, msg)
     loss.backward()
-    ref = load_synth(O.UformerAudio(drop_path_rate=0.0)).train()
-    rout = ref(x.cpu(), msg.cpu(), attack=attack, extract_from="attacked")
-    rloss, rterms = O.train_losses(rout, x.cpu(), msg.cpu())
-    rloss.backward()
+    names = ("decoder_wm.conv.blocks.0.mlp.linear1.0.weight", "decoder.decoderlayer_2.blocks.0.attn.proj.weight",
+             "encoder.encoderlayer_0.blocks.0.norm2.bias", "encoder_wm.t_conv2.weight")
+    # the oracle's pass over the 20 tiles (a minute of CPU) is the same for both parity modes — same tiles, same payload, same
+    # replayed AWGN stream (seed, step 1, B) — and is computed once
+    key = (x.cpu().double().sum().item(), msg.cpu().double().sum().item(), int(m._step_t.item()))
+    if _C5_ORACLE.get("key") != key:
+        ref = load_synth(O.UformerAudio(drop_path_rate=0.0)).train()
+        rout = ref(x.cpu(), msg.cpu(), attack=attack, extract_from="attacked")
+        rloss, rterms = O.train_losses(rout, x.cpu(), msg.cpu())
+        rloss.backward()
+        _C5_ORACLE.update(key=key, rout=[r.detach() for r in rout], rterms=torch.stack(rterms).detach(),
+                          grads={n: ref.get_parameter(n).grad.clone() for n in names})
+    rout, rterms, rgrads = _C5_ORACLE["rout"], _C5_ORACLE["rterms"], _C5_ORACLE["grads"]
     for o, r, k in zip(out, rout, ("stft_new", "noise", "wm_pred", "wm")):
-        assert rel(o, r.detach()) <= 2e-4, (k, rel(o, r.detach()))
-    np.testing.assert_allclose(torch.stack(terms).detach().cpu().numpy(), torch.stack(rterms).detach().numpy(), rtol=2e-4)
-    for n in ("decoder_wm.conv.blocks.0.mlp.linear1.0.weight", "decoder.decoderlayer_2.blocks.0.attn.proj.weight",
-              "encoder.encoderlayer_0.blocks.0.norm2.bias", "encoder_wm.t_conv2.weight"):
-        e = rel(m.get_parameter(n).grad, ref.get_parameter(n).grad)
+        assert rel(o, r) <= 2e-4, (k, rel(o, r))
+    np.testing.assert_allclose(torch.stack(terms).detach().cpu().numpy(), rterms.numpy(), rtol=2e-4)
+    for n in names:
+        e = rel(m.get_parameter(n).grad, rgrads[n])
         assert e <= 3e-3, (n, e)
     # payload: per-tile quadrants -> 64 x 64 image, thresholded (grayscale payload: compare the rounded images)
     got = wm.dataprep.payload_from_tiles(out[3].detach().round().clamp(0, 1), tpc).cpu()
-    want = wm.dataprep.payload_from_tiles(rout[3].detach().round().clamp(0, 1).cuda(), tpc).cpu()
+    want = wm.dataprep.payload_from_tiles(rout[3].round().clamp(0, 1).cuda(), tpc).cpu()
     assert torch.equal(got, want)
 
 
