@@ -835,7 +835,8 @@ int launch_tn(const WmGemm& g, hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
   const int64_t mn = (int64_t)g.M * g.N;
   const bool use_part = g.scratch && !(g.N & 3);
-  int ksplit = g.ksplit > 0 ? g.ksplit : ((use_part ? TN_TARGET : 768) + tiles - 1) / tiles;
+  static const int tn_target = [] { const char* v = getenv("WM_TN_TARGET"); const int t = v ? atoi(v) : 0; return t > 0 ? t : TN_TARGET; }();
+  int ksplit = g.ksplit > 0 ? g.ksplit : ((use_part ? tn_target : 768) + tiles - 1) / tiles;
   // a slice shorter than 512 tokens writes and re-reads more partial sums than it reads operands (128 x 128 x 8 B against
   // 256 rows x 2 B per token): measured at B = 24 (deep levels: 1.5 k - 6 k tokens), 29.15 -> 28.41 ms per step
   const int mk = use_part ? 512 : 256;
