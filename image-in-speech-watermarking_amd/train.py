@@ -202,7 +202,7 @@ class GradSync:
         send, gathered = self._xbuf[key]
         if bucket.is_cuda:
             ops.cast_bf16(bucket, send, n)
-            dist.all_gather_into_tensor(gathered, send, group=self.pg)
+            dist.all_gather_into_tensor(gathered.view(-1), send, group=self.pg)    # (flat output: gloo accepts no [world, n] view)
             if npad == n:
                 ops.sum_bf16_rows(gathered, bucket, self.world, n)
             else:

@@ -43,14 +43,17 @@ def test_gpus_flag_starts_the_ranks_itself():
 
 @pytest.mark.gpu
 def test_two_rank_rehearsal_of_config5_clips():
-    """`--gpus 2 --clip-seconds 10` (config 5's shape: 10-tile clips, 64 x 64 payload as quadrants) over the N-rank path."""
+    """`--gpus 2 --clip-seconds 10` (config 5's shape: 10-tile clips, 64 x 64 payload as quadrants) over the N-rank path, with the
+    bf16 gradient exchange (device path: wm_cast_bf16 -> all-gather -> wm_sum_bf16_rows; the other rehearsal uses the fp32 all-reduce)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--clip-seconds", "10",
-                        "--steps", "2", "--warmup", "1", "--batch", "10", "--no-cpu-baseline", "--no-kernel-timing"],
+                        "--steps", "2", "--warmup", "1", "--batch", "10", "--no-cpu-baseline", "--no-kernel-timing",
+                        "--grad-exchange", "bf16"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["baseline_config"] == 5 and line["config"]["global_tiles"] == 20
     assert "10 s 16 kHz clips" in line["config"]["workload"] and line["value"] > 0
+    assert line["allreduce"]["exchange"].startswith("bf16")
 
 
 @pytest.mark.gpu
