@@ -32,7 +32,8 @@ class WmGemm(C.Structure):
                 ("a_bf16", c_i32), ("b_bf16", c_i32), ("c_bf16", c_i32), ("gaux_bf16", c_i32),
                 ("gaux_raw", c_i32), ("scratch", c_f), ("scratch_floats", c_i64), ("defer", C.POINTER(WmReduceJob)),
                 ("ln_gamma", c_f), ("ln_beta", c_f), ("ln_mod", c_f), ("ln_out", c_f), ("ln_mean", c_f), ("ln_rstd", c_f),
-                ("ln_hw", c_i32), ("ln_shift", c_i32)]
+                ("ln_hw", c_i32), ("ln_shift", c_i32),
+                ("a_grid_n", c_i32), ("a_jump_k", c_i32), ("a_jump", c_i64), ("b_seg_cols", c_i32), ("b_seg_rows", c_i32 * 4)]
 
 
 class WmConv(C.Structure):
@@ -77,6 +78,14 @@ _SIGS = {
     "wm_leff_bwd": [c_f, c_i32] + [c_f] * 11 + [C.POINTER(WmReduceJob), c_i32, c_i32, c_i32, c_f],
     "wm_im2col_4x4s2": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_f],
     "wm_col2im_4x4s2": [c_f, c_i32, c_f, c_i32, c_i32, c_i32, c_f],
+    "wm_conv4x4s2_xg_rows": [c_i32, c_i32],
+    "wm_conv4x4s2_dyg_rows": [c_i32, c_i32],
+    "wm_conv4x4s2_grid_rows": [c_i32, c_i32],
+    "wm_conv4x4s2_x_to_grid": [c_f, c_f, c_i32, c_i32, c_i32, c_f],
+    "wm_conv4x4s2_dy_to_grid": [c_f, c_i32, c_f, c_i32, c_i32, c_i32, c_f],
+    "wm_conv4x4s2_grid_to_dx": [c_f, c_f, c_i32, c_i32, c_i32, c_f],
+    "wm_conv4x4s2_weights": [c_f, c_f, c_f, c_i32, c_f],
+    "wm_conv4x4s2_dweight": [c_f, c_f, c_i32, c_f],
     "wm_pixel_shuffle2": [c_f, c_i32, c_f, c_f, c_i32, c_i32, c_i32, c_i64, c_i32, c_f],
     "wm_pixel_unshuffle2": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_f],
     "wm_copy_cols": [c_f, c_i64, c_i32, c_f, c_i64, c_i32, c_i64, c_i32, c_i32, c_f],
@@ -162,7 +171,7 @@ def _load():
     for name, args in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError here = ABI drift between header and library
         fn.argtypes = args
-        fn.restype = C.c_int64 if name.endswith(("_floats", "_bytes")) else C.c_int
+        fn.restype = C.c_int64 if name.endswith(("_floats", "_bytes", "_rows")) else C.c_int
     return lib
 
 

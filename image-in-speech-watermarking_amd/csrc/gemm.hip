@@ -609,6 +609,7 @@ extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
   if (g.b_ones && !g.C2) return WM_EINVAL;
   if (g.kscale && (g.k_per_scale <= 0 || (g.k_per_scale & 3))) return WM_EINVAL;
   if (g.rowscale && g.rows_per_scale <= 0) return WM_EINVAL;
+  if ((g.a_grid_n || g.a_jump_k || g.b_seg_cols) && (g.mode != 1 || g.ln_out)) return WM_EINVAL;   // grid addressing: bf16 mode, plain epilogues
   hipStream_t st = static_cast<hipStream_t>(stream);
   wm_gemm_family_tls = WM_FAM_GENERIC;
   if (g.ln_out) {                                              // fused LayerNorm: only the kernels that hold whole rows
@@ -630,6 +631,7 @@ extern "C" int wm_gemm(const WmGemm* gp, void* stream) {
     if (rc >= 0) return rc;
     rc = wm_gemm_fast_bf16(g, st);
     if (rc >= 0) return rc;
+    if (g.a_grid_n || g.a_jump_k || g.b_seg_cols) return WM_EINVAL;    // grid addressing exists in the fast kernels only
   }
   if (g.mode == 1) {
     if (g.a_bf16 && g.b_bf16) return dispatch<__bf16, __bf16, __bf16, false, 64>(g, g.ksplit, st);

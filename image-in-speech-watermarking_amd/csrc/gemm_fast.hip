@@ -106,7 +106,8 @@ template <typename ST, int R, int BK, bool GELU, bool SPLIT = false> struct KcSt
   uint32_t rowok;
   int kq, soff;
   bool edge;                                                 // some row of this workgroup's tile is outside the matrix
-  __device__ __forceinline__ void init(const void* p, int64_t ld, int row0, int rmax, int k0, int tid) {
+  // grid_n > 0: row (b, Y, X) of the compact n x n enumeration lives at row b (n+2)^2 + (Y+1)(n+2) + X+1 of the operand (WmGemm::a_grid_n)
+  __device__ __forceinline__ void init(const void* p, int64_t ld, int row0, int rmax, int k0, int tid, int grid_n = 0) {
     const int r0 = tid / CPR;
     kq = E * (tid % CPR); rowok = 0; soff = r0 * LD + kq;
     edge = row0 + R > rmax;
@@ -114,8 +115,17 @@ template <typename ST, int R, int BK, bool GELU, bool SPLIT = false> struct KcSt
     for (int q = 0; q < NP; ++q) {
       const int row = row0 + r0 + RPP * q;
       if (row < rmax) rowok |= 1u << q;
-      ptr[q] = static_cast<const ST*>(p) + (int64_t)min(row, rmax - 1) * ld + k0 + kq;
+      int64_t rr = min(row, rmax - 1);
+      if (grid_n > 0) {
+        const int nn = grid_n * grid_n, b = (int)rr / nn, t = (int)rr - b * nn, Y = t / grid_n, X = t - Y * grid_n;
+        rr = (int64_t)b * (grid_n + 2) * (grid_n + 2) + (Y + 1) * (grid_n + 2) + X + 1;
+      }
+      ptr[q] = static_cast<const ST*>(p) + rr * ld + k0 + kq;
     }
+  }
+  __device__ __forceinline__ void jump(int64_t d) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) ptr[q] += d;
   }
   __device__ __forceinline__ void load_full() {
 #pragma unroll
@@ -345,7 +355,8 @@ __global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 && EPI != 4 ? 3 :
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   KcStage<AT, BM, BK, A_GELU, SPLIT> sa;
-  sa.init(g.A, g.lda, m0, g.M, 0, tid);
+  sa.init(g.A, g.lda, m0, g.M, 0, tid, g.a_grid_n);
+  const int jump_tile = g.a_jump_k > 0 ? g.a_jump_k / BK : -1;   // the tile whose load is followed by the pointer jump (host: a_jump_k % 128 == 0)
   KcStage<BT, BN, BK, false, SPLIT> sbk;
   TrStage<BT, BN, BK, false, SPLIT> sbt;
   if constexpr (B_TR) sbt.init(g.B, g.ldb, n0, g.N, 0, tid); else sbk.init(g.B, g.ldb, n0, g.N, 0, tid);
@@ -353,6 +364,7 @@ __global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 && EPI != 4 ? 3 :
   const int nfull = K / BK, ntiles = (K + BK - 1) / BK;     // tiles [0, nfull) lie completely inside K
   if (nfull > 0) {
     sa.load_full();
+    if (jump_tile == 1) sa.jump(g.a_jump);
     if constexpr (B_TR) sbt.load_full(); else sbk.load_full();
     sa.store_full(As);
     if constexpr (B_TR) sbt.store_full(Bs, false); else sbk.store_full(Bs);
@@ -368,6 +380,7 @@ __global__ __launch_bounds__(256, (sizeof(AT) == 2 && EPI != 3 && EPI != 4 ? 3 :
     const int nx = t + 1;
     if (nx < nfull) {
       sa.load_full();
+      if (nx + 1 == jump_tile) sa.jump(g.a_jump);             // (tiles [0, jump_tile) are loaded: the rest lie a_jump further on)
       if constexpr (B_TR) sbt.load_full(); else sbk.load_full();
     } else if (nx < ntiles) {
       sa.load_tail(nx * BK, K);
@@ -591,7 +604,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WmGemm g, const int 
   TrStage<AT, BM, TBK, false, SPLIT> sa;
   TrStage<BT, BN, TBK, B_GELU, SPLIT> sb;
   sa.init(g.A, g.lda, m0, g.M, kbeg, tid);
-  sb.init(g.B, g.ldb, n0, g.N, kbeg, tid);
+  const BT* Bp = static_cast<const BT*>(g.B);
+  if (g.b_seg_cols > 0) {                                    // column block of this tile: rows further down, columns of the stored row
+    const int seg = n0 / g.b_seg_cols;
+    Bp += (int64_t)g.b_seg_rows[seg] * g.ldb - (int64_t)seg * g.b_seg_cols;
+  }
+  sb.init(Bp, g.ldb, n0, g.N, kbeg, tid);
   const bool scaled = g.kscale != nullptr;                   // host guarantees k_per_scale % TBK == 0 and klen % TBK == 0
   const int nfull = (kend - kbeg) / TBK, ntiles = (kend - kbeg + TBK - 1) / TBK;
   if (scaled) sa.load_scale(g.kscale, g.k_per_scale, kbeg);
@@ -912,6 +930,13 @@ int wm_gemm_fast_bf16(const WmGemm& g, hipStream_t st) {
   if (g.defer) *g.defer = WmReduceJob{};                       // count 0 unless a split-K launch fills it in
   if (g.mode != 1) return -1;
   const int ea = g.a_bf16 ? 8 : 4, eb = g.b_bf16 ? 8 : 4;
+  if (g.a_grid_n || g.a_jump_k) {                              // grid addressing of A: K-contiguous bf16 A, whole 64 / 128-deep tiles on both sides of the jump
+    if (!g.a_kc || !g.a_bf16 || g.a_op || g.atomic_out || (g.K % 128) || (g.a_jump_k % 128) || g.a_jump_k >= g.K || (g.a_jump % 8)) return -1;
+    if (g.a_grid_n && (g.M % (g.a_grid_n * g.a_grid_n))) return -1;
+  }
+  if (g.b_seg_cols) {                                          // ... of B: weight gradient only, tiles never straddle a column block
+    if (g.a_kc || g.b_kc || !g.atomic_out || !g.b_bf16 || (g.b_seg_cols % 128) || g.N > 4 * g.b_seg_cols) return -1;
+  }
   if (!g.a_kc && !g.b_kc && g.atomic_out && !g.a_op && !g.c_bf16) {          // weight gradient
     if ((g.M % ea) || (g.N % eb) || (g.lda % ea) || (g.ldb % eb) || g.M < ea || g.N < eb) return -1;
     if (g.kscale && (g.k_per_scale <= 0 || g.k_per_scale % TBK)) return -1;    // one scale per k tile (TrStage::load_scale)

@@ -30,7 +30,8 @@ def _bf(t):
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=1, b_kc=1, a_op=0, b_op=0, bias=None, res=None, ldr=0,
          rowscale=None, rows_per_scale=0, kscale=None, k_per_scale=0, gaux=None, ldg=0, b_ones=False, C2=None,
-         atomic_out=False, ksplit=0, mode=MODE_FP32, gaux_raw=False, scratch=None, defer=None, ln=None):
+         atomic_out=False, ksplit=0, mode=MODE_FP32, gaux_raw=False, scratch=None, defer=None, ln=None,
+         a_grid_n=0, a_jump_k=0, a_jump=0, b_seg_cols=0, b_seg_rows=(0, 0, 0, 0)):
     lnf = (None, None, None, None, None, None, 0, 0)
     if ln is not None:
         gamma, beta, mod, out, mean, rstd, hw, shift = ln
@@ -40,7 +41,8 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=1, b_kc=1, a_op=0, b_op=0, bia
     g = WmGemm(ptr(A), ptr(B), ptr(Cout), M, N, K, lda, ldb, ldc, a_kc, b_kc, a_op, b_op, ptr(bias), ptr(res), ldr,
                ptr(rowscale), rows_per_scale, ptr(kscale), k_per_scale, ptr(gaux), ldg, int(b_ones), ptr(C2),
                int(atomic_out), ksplit, mode, _bf(A), _bf(B), _bf(Cout), _bf(gaux), int(gaux_raw),
-               ptr(scratch), scratch.numel() if scratch is not None else 0, defer, *lnf)
+               ptr(scratch), scratch.numel() if scratch is not None else 0, defer, *lnf,
+               int(a_grid_n), int(a_jump_k), int(a_jump), int(b_seg_cols), (C.c_int32 * 4)(*[int(v) for v in b_seg_rows]))
     check(lib.wm_gemm(C.byref(g), _stream()), f"wm_gemm(M={M},N={N},K={K})")
 
 
@@ -254,6 +256,49 @@ def cast_bf16(src, dst, n):
 def sum_bf16_rows(src, dst, rows, n):
     """dst[i] (fp32) = sum over the `rows` bf16 rows of src[r, i]."""
     check(lib.wm_sum_bf16_rows(ptr(src), ptr(dst), rows, n, _stream()), "wm_sum_bf16_rows")
+
+
+def down_direct_ok(hw, Cc):
+    """Downsample without the im2col image (csrc/conv_grid.hip + grid addressing of wm_gemm): bf16 mode, C a multiple of 32."""
+    import os
+    return os.environ.get("WM_DOWN_DIRECT", "1") != "0" and hw % 2 == 0 and hw >= 4 and Cc % 32 == 0
+
+
+def conv_weights(w, Cc):
+    """weight [2C, C, 4, 4] fp32 -> (w_fwd [2C, 16C], w_dx [4C, 8C]) bf16 in 2 x 2-block order."""
+    w_fwd = torch.empty(2 * Cc, 16 * Cc, device=w.device, dtype=torch.bfloat16)
+    w_dx = torch.empty(4 * Cc, 8 * Cc, device=w.device, dtype=torch.bfloat16)
+    check(lib.wm_conv4x4s2_weights(ptr(w), ptr(w_fwd), ptr(w_dx), Cc, _stream()), "wm_conv4x4s2_weights")
+    return w_fwd, w_dx
+
+
+def down_direct_fwd(x, w_fwd, bias, y, B, hw, Cc):
+    """y [B (hw/2)^2, 2C] = Conv2d(4, 2, 1)(x [B, hw, hw, C]) + bias; returns the grid image of x (kept for the weight gradient)."""
+    n, Wg = hw // 2, hw // 2 + 2
+    xg = torch.empty(int(lib.wm_conv4x4s2_xg_rows(B, hw)), 4 * Cc, device=x.device, dtype=torch.bfloat16)
+    check(lib.wm_conv4x4s2_x_to_grid(ptr(x), ptr(xg), B, hw, Cc, _stream()), "wm_conv4x4s2_x_to_grid")
+    gemm(xg, w_fwd, y, B * n * n, 2 * Cc, 16 * Cc, 4 * Cc, 16 * Cc, 2 * Cc, 1, 1, bias=bias, mode=MODE_BF16,
+         a_grid_n=n, a_jump_k=8 * Cc, a_jump=(Wg - 2) * 4 * Cc)
+    return xg
+
+
+def down_direct_bwd(dy, xg, w_dx, dx, dw_fwd_order, db, B, hw, Cc, scratch=None):
+    """dx [B, hw, hw, C] fp32 (written), dw_fwd_order [2C, 16C] fp32 += , db [2C] += from dy [B (hw/2)^2, 2C] (fp32 or bf16)."""
+    n, Wg = hw // 2, hw // 2 + 2
+    Mg = int(lib.wm_conv4x4s2_grid_rows(B, hw))
+    dyg = torch.empty(int(lib.wm_conv4x4s2_dyg_rows(B, hw)), 2 * Cc, device=dy.device, dtype=torch.bfloat16)
+    check(lib.wm_conv4x4s2_dy_to_grid(ptr(dy), _bf(dy), ptr(dyg), B, hw, Cc, _stream()), "wm_conv4x4s2_dy_to_grid")
+    dxg = torch.empty(Mg, 4 * Cc, device=dy.device, dtype=torch.bfloat16)
+    # rows g - Wg - 1, g - Wg | g - 1, g of the bordered gradient (the buffer starts Wg + 1 rows before grid row 0)
+    gemm(dyg, w_dx, dxg, Mg, 4 * Cc, 8 * Cc, 2 * Cc, 8 * Cc, 4 * Cc, 1, 1, mode=MODE_BF16, a_jump_k=4 * Cc, a_jump=(Wg - 2) * 2 * Cc)
+    check(lib.wm_conv4x4s2_grid_to_dx(ptr(dxg), ptr(dx), B, hw, Cc, _stream()), "wm_conv4x4s2_grid_to_dx")
+    dyd = dyg[Wg + 1:]                                            # the grid rows themselves: the token axis of the weight gradient
+    gemm(dyd, xg, dw_fwd_order, 2 * Cc, 16 * Cc, Mg, 2 * Cc, 4 * Cc, 16 * Cc, 0, 0, b_ones=db is not None, C2=db, atomic_out=True,
+         mode=MODE_BF16, scratch=scratch, b_seg_cols=4 * Cc, b_seg_rows=(0, 1, Wg, Wg + 1))
+
+
+def conv_dweight(dw_fwd_order, grad, Cc):
+    check(lib.wm_conv4x4s2_dweight(ptr(dw_fwd_order), ptr(grad), Cc, _stream()), "wm_conv4x4s2_dweight")
 
 
 def transpose_cast_jobs(arena, arena_t, jobs, njobs, total_tiles):

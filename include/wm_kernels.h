@@ -73,6 +73,17 @@ typedef struct WmGemm {
   const float* ln_gamma; const float* ln_beta; const float* ln_mod;
   void* ln_out; float* ln_mean; float* ln_rstd;
   int32_t ln_hw, ln_shift;
+  /* Operand addressing of the strided convolution without an im2col image (Downsample, model.py:759-775; mode 1, bf16 operands,
+   * the 128 x 128-family kernels only; all 0 = plain GEMM).  The layer input lives as 2 x 2 pixel blocks on a grid of
+   * (n + 2)^2 rows per image (wm_conv4x4s2_* below); then every operand row of the three products is a grid row at a constant
+   * row offset from its partner's:
+   *   a_grid_n   > 0: A row m = (image b, Y, X) of the compact n x n enumeration is grid row b (n+2)^2 + (Y+1)(n+2) + X+1 (a_kc);
+   *   a_jump_k   > 0: after a_jump_k elements of K the A pointer skips a_jump further elements (a_kc; a multiple of 128 / 8);
+   *   b_seg_cols > 0: (weight gradient) column block s = n / b_seg_cols of B is read from rows b_seg_rows[s] further down,
+   *                   its columns are n - s b_seg_cols of the stored row (b_seg_cols a multiple of 128).                        */
+  int32_t a_grid_n, a_jump_k;
+  int64_t a_jump;
+  int32_t b_seg_cols, b_seg_rows[4];
 } WmGemm;
 int32_t wm_gemm_ln_fusable(int32_t M, int32_t N, int32_t K, int32_t mode, int32_t a_bf16);
 int64_t wm_gemm_scratch_floats(void);
@@ -180,6 +191,20 @@ int wm_leff_bwd(const void* dy, int32_t dy_bf16, const float* rowscale /* [B] or
 /* ---- data movement for Downsample (conv4x4 s2 p1, model.py:763) / Upsample (convT2x2 s2, :789) */
 int wm_im2col_4x4s2(const float* x, void* cols, int32_t cols_bf16, int32_t B, int32_t hw, int32_t C, void* stream);
 int wm_col2im_4x4s2(const void* dcols, int32_t dcols_bf16, float* dx, int32_t B, int32_t hw, int32_t C, void* stream);
+/* The same layer WITHOUT the im2col image (csrc/conv_grid.hip; bf16 mode): the input as 2 x 2 pixel blocks on a grid of (hw/2 + 2)^2 rows
+ * per image, so that the forward, dX and dW products are ordinary wm_gemm launches with grid addressing (WmGemm::a_grid_n, a_jump_k,
+ * b_seg_cols) and these layout passes replace im2col / col2im:  x [B,hw,hw,C] fp32 -> xg [wm_conv4x4s2_xg_rows][4C] bf16;
+ * dy [B (hw/2)^2, 2C] (fp32 or bf16) -> dyg [wm_conv4x4s2_dyg_rows][2C] bf16 (zero border, hw/2 + 3 zero rows in front);
+ * dxg [wm_conv4x4s2_grid_rows][4C] bf16 -> dx [B,hw,hw,C] fp32;  weight [2C,C,4,4] fp32 -> w_fwd [2C,16C] and w_dx [4C,8C] bf16 in
+ * block order; a weight gradient in w_fwd order added into grad [2C,C,4,4].                                                         */
+int64_t wm_conv4x4s2_xg_rows(int32_t B, int32_t hw);
+int64_t wm_conv4x4s2_dyg_rows(int32_t B, int32_t hw);
+int64_t wm_conv4x4s2_grid_rows(int32_t B, int32_t hw);
+int wm_conv4x4s2_x_to_grid(const float* x, void* xg, int32_t B, int32_t hw, int32_t C, void* stream);
+int wm_conv4x4s2_dy_to_grid(const void* dy, int32_t dy_bf16, void* dyg, int32_t B, int32_t hw, int32_t C, void* stream);
+int wm_conv4x4s2_grid_to_dx(const void* dxg, float* dx, int32_t B, int32_t hw, int32_t C, void* stream);
+int wm_conv4x4s2_weights(const float* w, void* w_fwd, void* w_dx, int32_t C, void* stream);
+int wm_conv4x4s2_dweight(const float* dw_fwd_order, float* grad, int32_t C, void* stream);
 /* y4: [B*hw*hw, 4*Co] columns ordered (di,dj,o)  <->  dst[B,(2hw)^2, ldd] channels [c0, c0+Co) */
 int wm_pixel_shuffle2(const void* y4, int32_t y4_bf16, const float* bias /* [Co] or NULL */, float* dst, int32_t B,
                       int32_t hw, int32_t Co, int64_t ldd, int32_t c0, void* stream);
