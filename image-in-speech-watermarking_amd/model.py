@@ -639,6 +639,13 @@ class UformerAudio(nn.Module):
     def _down_fwd(self, pre, x, B, hw, C):
         P, dev, mode = self._views, x.device, self._mode()
         Mo = B * (hw // 2) ** 2
+        if self.compute_mode == "bf16" and ops.down_direct_ok(hw, C):
+            # no im2col image: the input as 2 x 2 pixel blocks on a grid (2 C bytes per input token instead of 8 C), the three
+            # products as GEMMs with grid addressing (csrc/conv_grid.hip); the grid image is kept for the weight gradient
+            w_fwd, w_dx = ops.conv_weights(P[pre + "weight"], C)
+            y = _E(dev, Mo, 2 * C)
+            xg = ops.down_direct_fwd(x, w_fwd, P[pre + "bias"], y, B, hw, C)
+            return y, (pre, x, B, hw, C, w_dx, xg, True)
         cols = self._H(dev, Mo, 16 * C)
         ops.im2col(x, cols, B, hw, C)
         w2 = self._H(dev, 2 * C, 16 * C)
@@ -650,10 +657,19 @@ class UformerAudio(nn.Module):
         return y, (pre, x, B, hw, C, w2, cols)
 
     def _down_bwd(self, sv, dy, dyh=None):
-        pre, x, B, hw, C, w2, cols = sv
-        G, dev, mode = self._gviews, x.device, self._mode()
-        Mo = dy.shape[0]
+        G, dev, mode = self._gviews, dy.device, self._mode()
         dyg = dyh if dyh is not None else dy                       # GEMM operand: the bf16 copy when there is one
+        if len(sv) == 8:                                           # direct form (see _down_fwd)
+            pre, x, B, hw, C, w_dx, xg, _ = sv
+            dx = _E(dev, x.shape[0], C)
+            dwf = _Z(dev, 2 * C, 16 * C)
+            ops.down_direct_bwd(dyg, xg, w_dx, dx, dwf, G[pre + "bias"], B, hw, C, scratch=self._gemm_scratch(dev))
+            ops.conv_dweight(dwf, G[pre + "weight"], C)
+            if self._grad_ready is not None:
+                self._grad_ready(*self._owner_range[pre])
+            return dx
+        pre, x, B, hw, C, w2, cols = sv
+        Mo = dy.shape[0]
         dcols = self._H(dev, Mo, 16 * C)
         ops.linear_bwd_input(dyg, w2, dcols, mode)
         dx = _E(dev, x.shape[0], C)

@@ -272,11 +272,23 @@ def conv_weights(w, Cc):
     return w_fwd, w_dx
 
 
+def conv_x_to_grid(x, xg, B, hw, Cc):
+    check(lib.wm_conv4x4s2_x_to_grid(ptr(x), ptr(xg), B, hw, Cc, _stream()), "wm_conv4x4s2_x_to_grid")
+
+
+def conv_dy_to_grid(dy, dyg, B, hw, Cc):
+    check(lib.wm_conv4x4s2_dy_to_grid(ptr(dy), _bf(dy), ptr(dyg), B, hw, Cc, _stream()), "wm_conv4x4s2_dy_to_grid")
+
+
+def conv_grid_to_dx(dxg, dx, B, hw, Cc):
+    check(lib.wm_conv4x4s2_grid_to_dx(ptr(dxg), ptr(dx), B, hw, Cc, _stream()), "wm_conv4x4s2_grid_to_dx")
+
+
 def down_direct_fwd(x, w_fwd, bias, y, B, hw, Cc):
     """y [B (hw/2)^2, 2C] = Conv2d(4, 2, 1)(x [B, hw, hw, C]) + bias; returns the grid image of x (kept for the weight gradient)."""
     n, Wg = hw // 2, hw // 2 + 2
     xg = torch.empty(int(lib.wm_conv4x4s2_xg_rows(B, hw)), 4 * Cc, device=x.device, dtype=torch.bfloat16)
-    check(lib.wm_conv4x4s2_x_to_grid(ptr(x), ptr(xg), B, hw, Cc, _stream()), "wm_conv4x4s2_x_to_grid")
+    conv_x_to_grid(x, xg, B, hw, Cc)
     gemm(xg, w_fwd, y, B * n * n, 2 * Cc, 16 * Cc, 4 * Cc, 16 * Cc, 2 * Cc, 1, 1, bias=bias, mode=MODE_BF16,
          a_grid_n=n, a_jump_k=8 * Cc, a_jump=(Wg - 2) * 4 * Cc)
     return xg
@@ -287,11 +299,11 @@ def down_direct_bwd(dy, xg, w_dx, dx, dw_fwd_order, db, B, hw, Cc, scratch=None)
     n, Wg = hw // 2, hw // 2 + 2
     Mg = int(lib.wm_conv4x4s2_grid_rows(B, hw))
     dyg = torch.empty(int(lib.wm_conv4x4s2_dyg_rows(B, hw)), 2 * Cc, device=dy.device, dtype=torch.bfloat16)
-    check(lib.wm_conv4x4s2_dy_to_grid(ptr(dy), _bf(dy), ptr(dyg), B, hw, Cc, _stream()), "wm_conv4x4s2_dy_to_grid")
+    conv_dy_to_grid(dy, dyg, B, hw, Cc)
     dxg = torch.empty(Mg, 4 * Cc, device=dy.device, dtype=torch.bfloat16)
     # rows g - Wg - 1, g - Wg | g - 1, g of the bordered gradient (the buffer starts Wg + 1 rows before grid row 0)
     gemm(dyg, w_dx, dxg, Mg, 4 * Cc, 8 * Cc, 2 * Cc, 8 * Cc, 4 * Cc, 1, 1, mode=MODE_BF16, a_jump_k=4 * Cc, a_jump=(Wg - 2) * 2 * Cc)
-    check(lib.wm_conv4x4s2_grid_to_dx(ptr(dxg), ptr(dx), B, hw, Cc, _stream()), "wm_conv4x4s2_grid_to_dx")
+    conv_grid_to_dx(dxg, dx, B, hw, Cc)
     dyd = dyg[Wg + 1:]                                            # the grid rows themselves: the token axis of the weight gradient
     gemm(dyd, xg, dw_fwd_order, 2 * Cc, 16 * Cc, Mg, 2 * Cc, 4 * Cc, 16 * Cc, 0, 0, b_ones=db is not None, C2=db, atomic_out=True,
          mode=MODE_BF16, scratch=scratch, b_seg_cols=4 * Cc, b_seg_rows=(0, 1, Wg, Wg + 1))

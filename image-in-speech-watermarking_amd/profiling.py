@@ -20,6 +20,10 @@ def _gemm_cost(a):
     kw = a[-1]
     flops = 2.0 * M * N * K
     byts = A.element_size() * M * K + B.element_size() * N * K + C.element_size() * M * N
+    if kw.get("a_grid_n") or kw.get("a_jump_k"):              # grid addressing: the rows of a K range overlap, the operand is read once
+        byts += A.element_size() * (A.numel() - M * K)
+    if kw.get("b_seg_cols"):
+        byts += B.element_size() * (B.numel() - N * K)
     if kw.get("res") is not None:
         byts += 4.0 * M * N
     if kw.get("gaux") is not None:
@@ -56,6 +60,9 @@ COST = {
     "layernorm_bwd": lambda dy, x, *a, **k: (16.0 * x.numel(), (12.0 + dy.element_size() + (2.0 if k.get("dx_bf16") is not None else 0.0)) * x.numel()),
     "im2col": lambda x, cols, *a: (0.0, 4.0 * (x.numel() + cols.numel())),
     "col2im": lambda dc, dx, *a: (0.0, 4.0 * (dx.numel() + dc.numel())),
+    "conv_x_to_grid": lambda x, xg, *a: (0.0, 4.0 * x.numel() + 2.0 * xg.numel()),
+    "conv_dy_to_grid": lambda dy, dyg, *a: (0.0, float(dy.element_size()) * dy.numel() + 2.0 * dyg.numel()),
+    "conv_grid_to_dx": lambda dxg, dx, *a: (0.0, 2.0 * dxg.numel() + 4.0 * dx.numel()),
     "pixel_shuffle": lambda y4, *a: (0.0, 8.0 * y4.numel()),
     "pixel_unshuffle": lambda ds, dy4, *a: (0.0, 8.0 * dy4.numel()),
     "copy_cols": lambda src, lds, s0, dst, ldd, c0, rows, C, accumulate=False: (0.0, 8.0 * rows * C),
@@ -110,7 +117,8 @@ class KernelTimer:
         for name in dir(ops):
             fn = getattr(ops, name)
             if not callable(fn) or name.startswith("_") or name in ("check", "ptr", "conv_desc", "linear_fwd", "ln_fusable",
-                                                                     "linear_bwd_input", "linear_bwd_weight"):
+                                                                     "linear_bwd_input", "linear_bwd_weight", "down_direct_ok",
+                                                                     "down_direct_fwd", "down_direct_bwd", "conv_weights"):
                 continue
             if getattr(fn, "__module__", "") != ops.__name__:
                 continue
