@@ -22,6 +22,8 @@
 extern "C" {
 #endif
 
+/* 7 (round 4): wm_attn_half_*, wm_leff_*, wm_sum_bf16_rows, wm_conv4x4s2_*; `terms` argument of the n_fft = 255 transforms;
+ * WmGemm grew by the grid-addressing fields at its END (a binding built against version 6 passes a shorter struct: rebuild it) */
 int wm_abi_version(void);
 
 /* ---- GEMM with fused prologue/epilogue -----------------------------------------------------
