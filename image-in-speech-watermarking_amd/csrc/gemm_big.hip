@@ -345,7 +345,8 @@ int wm_gemm_big_tn_bf16(const WmGemm& g, hipStream_t st) {
   const char* off = getenv("WM_GEMM_BIG_OFF");
   if (off && (off[0] == '1' || off[0] == '2')) return -1;          // 2: the weight-gradient kernel alone
   if (g.mode != 1 || g.a_kc || g.b_kc || !g.a_bf16 || !g.b_bf16 || g.a_op || g.b_op || !g.atomic_out || g.c_bf16 || g.kscale) return -1;
-  if (g.a_grid_n || g.a_jump_k || g.b_seg_cols) return -1;
+  if (g.a_grid_n || g.a_jump_k) return -1;
+  if (g.b_seg_cols && ((g.b_seg_cols % 256) || g.N > 4 * g.b_seg_cols || !use_pp())) return -1;   // (a 256-wide tile inside one column block)
   if ((g.M % 256) || (g.N % 256) || (g.K % 64) || (g.lda % 8) || (g.ldb % 8) || !al16(g.A) || !al16(g.B)) return -1;
   const int tiles_m = g.M / 256, tiles_n = g.N / 256, tiles = tiles_m * tiles_n;
   // one or three output tiles (proj / qkv at C = 256) would mean 86 - 256 token ranges of a few k steps each and as many

@@ -220,6 +220,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const WmGemm g, cons
   for (int q = 0; q < 2; ++q) {
     pa[q] = static_cast<const __bf16*>(g.A) + (int64_t)(kbeg + 16 * q + lrow) * g.lda + m0 + 8 * chunk;
     pb[q] = static_cast<const __bf16*>(g.B) + (int64_t)(kbeg + 16 * q + lrow) * g.ldb + n0 + 8 * chunk;
+    if (g.b_seg_cols > 0) {                                      // grid addressing (WmGemm::b_seg_cols): this tile's column block lies rows further down
+      const int seg = n0 / g.b_seg_cols;
+      pb[q] += (int64_t)g.b_seg_rows[seg] * g.ldb - (int64_t)seg * g.b_seg_cols;
+    }
   }
   const int64_t sa = (int64_t)SK * g.lda, sb = (int64_t)SK * g.ldb;
   auto request = [&](int stage) {

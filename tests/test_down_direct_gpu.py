@@ -30,7 +30,8 @@ def rel(a, b):
 
 # (B, hw, C): the four Downsample layers of a trunk (hw 128 / 64 / 32 / 16 with C 32 / 64 / 128 / 256) and small cases whose grid
 # rows are not multiples of the GEMM tile (B (hw/2 + 2)^2 = 3 * 36, 5 * 100)
-SHAPES = [(3, 8, 32), (5, 16, 64), (2, 128, 32), (2, 64, 64), (4, 32, 128), (8, 16, 256)]
+# (16, 32, 128) / (48, 16, 256): enough grid rows (>= 4096, a multiple of 64) for the weight gradient to take the 256 x 256 kernel
+SHAPES = [(3, 8, 32), (5, 16, 64), (2, 128, 32), (2, 64, 64), (4, 32, 128), (8, 16, 256), (16, 32, 128), (48, 16, 256)]
 
 
 @pytest.mark.parametrize("B,hw,C", SHAPES)
@@ -67,7 +68,8 @@ def test_direct_downsample_fwd_dx_dw(wm, B, hw, C):
         assert e <= 1e-3, f"dW {e:.3e}"
         e = rel(db, bd.grad)
         assert e <= 1e-3, f"db {e:.3e}"
-    assert wm.lib.wm_last_gemm_family() == 2                              # the weight gradient ran on gemm_tn_kernel (grid addressing)
+    big = (B, hw, C) in ((16, 32, 128), (48, 16, 256))
+    assert wm.lib.wm_last_gemm_family() == (4 if big else 2)              # weight gradient: gemm_tn_pp_kernel / gemm_tn_kernel, both with grid addressing
 
 
 def test_grid_addressing_is_refused_where_it_does_not_exist(wm):
