@@ -66,6 +66,11 @@ def parse_args():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="run the N-rank code path with every rank on GPU 0 over gloo (a functional rehearsal on a one-GPU "
                          "box: RCCL refuses two ranks per device; the numbers mean nothing)")
+    ap.add_argument("--rehearse-rccl", action="store_true",
+                    help="--gpus 1 only: run the N-rank call sequence (chain of graphs cut at the gradient buckets, every bucket's "
+                         "collective really issued on the side stream) on a ONE-rank RCCL process group: the sum over one rank is the "
+                         "identity, so the losses equal the plain run's; what it shows on a one-GPU box is that RCCL takes the calls "
+                         "between the graph replays and how long the host needs to issue one step (allreduce.host_issue)")
     return ap.parse_args()
 
 
@@ -204,9 +209,10 @@ def usable_cores():
     return phys, why
 
 
-def cpu_baseline(attacked, batch=4, steps=3, threads=None, budget_s=None):
+def cpu_baseline(attacked, batch=4, steps=8, threads=None, budget_s=None):
     """The oracle (CPU restatement, parity-pinned to the reference) timed on this box's host cores: same step definition
-    (zero_grad -> fwd -> attacks -> loss -> bwd -> AdamW), fp32, train mode.  Bounded sample so the run stays in minutes.
+    (zero_grad -> fwd -> attacks -> loss -> bwd -> AdamW), fp32, train mode.  Bounded sample (8 timed steps of 4 tiles: 12-14 s of
+    CPU work at the measured 1.5 s per step) so the run stays in minutes.
     threads: None = the 16 threads of the 1-GPU box's CPU share (the primary leg); a number = that many (the all-cores leg)."""
     import torch
     from oracle import uformer_wm as O
@@ -331,6 +337,18 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if a.rehearse_rccl:
+        if world != 1:
+            raise SystemExit("bench.py --rehearse-rccl is the ONE-rank rehearsal (--gpus 1)")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        a.no_reference_batch = a.no_identity_leg = a.no_parity_mode_leg = a.no_secondary_legs = True
+        a.no_cpu_baseline = a.no_kernel_timing = True
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if a.rehearse_one_gpu:
@@ -356,7 +374,7 @@ def main():
         ber = cpu_baseline_parity(wm, net, x, msg)               # before any optimiser step: weights = the synthetic init
 
     step = wm.TrainStep(net, opt, a.batch, attack=attack, extract_from=extract_from, use_graph=not a.no_graph,
-                        segmented=a.segmented, grad_exchange=a.grad_exchange)
+                        segmented=a.segmented, grad_exchange=a.grad_exchange, loopback=a.rehearse_rccl)
 
     def barrier():
         if world > 1:
@@ -383,11 +401,17 @@ def main():
     used_graph, segmented = step.use_graph, step.segmented
     n_graphs = len(step._segments[0]) if step._segments else 1
     allreduce = None
-    if world > 1:
-        # per-bucket gradient all-reduce time on the side stream (3 more steps; events on the communication stream)
+    if world > 1 or a.rehearse_rccl:
+        # per-bucket gradient all-reduce time on the side stream (5 more steps; events on the communication stream) and the time
+        # the host needs to issue one step (its graph replays and the collectives between them): the chain only keeps the GPU
+        # busy while that stays well below the step itself (config 5: 26 ms per step)
         step.sync.timing = []
-        for _ in range(3):
+        barrier()
+        step.host_timing = []
+        for _ in range(5):
             step.step(x, msg)
+        host = list(step.host_timing)
+        step.host_timing = None
         barrier()
         per = {}
         for lo, hi, s, e in step.sync.timing:
@@ -403,6 +427,13 @@ def main():
             for (lo, hi), t in per.items()],
             "xgmi_link_GBps": 153, "bucket_target_MB": round(step.sync.bucket_elems * 4 / 2 ** 20, 1),
             "exposed_tail_MB": round(sum((hi - lo) for (lo, hi) in list(per)[-2:]) * 4 / 1e6, 1)}
+        if host:
+            # the first of the five starts on an idle queue; later ones include any wait for queue space behind the running step
+            allreduce["host_issue"] = {"ms_per_step_first": round(host[0] * 1e3, 3), "ms_per_step_median": round(statistics.median(host) * 1e3, 3),
+                                       "graphs": n_graphs, "collectives": len(per),
+                                       "frac_of_step_first": round(host[0] / (dt / a.steps), 4)}
+        if a.rehearse_rccl:
+            allreduce["rehearsal"] = "ONE rank on RCCL (loopback): call sequence and host issue time only, the bus figures mean nothing"
     # the captured step holds 0.56 GB per tile; the legs below build their own steps at the same batch: give the memory back first
     step.release()
     ref_batch = identity = None

@@ -6,6 +6,8 @@ captured once into a hipGraph and replayed.  Data parallel: one process per GPU,
 all-reduced over RCCL in three contiguous slices (extractor / decoder / encoder) on a side stream, each
 launched as soon as its part of backward has finished so the xGMI transfer overlaps the remaining backward.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -139,7 +141,19 @@ class GradSync:
         self.bucket_elems = max(int(bucket_bytes) // 4, 1)
         self.timing = None                                      # bench.py: list of (lo, hi, start event, stop event)
         self.force = False                                      # tests / rehearsals: run the bucket logic on one rank too
+        self.loopback = False                                   # ... and issue its collectives on a one-rank group (enable_loopback)
         self.reset()
+
+    def enable_loopback(self):
+        """One-rank rehearsal of the N-rank call sequence: the bucket logic runs (``force``) and every collective is really
+        issued, on the side stream, on the one-rank process group the caller has initialised (RCCL accepts a single rank; the
+        sum over one rank is the identity, so the step's results do not change).  What it exercises on a one-GPU box is the
+        RCCL launches between the graph replays, the stream hand-overs and the bf16 exchange's device path."""
+        if not dist.is_initialized() or self.world != 1:
+            raise RuntimeError("enable_loopback needs an initialised process group of exactly one rank")
+        self.force = self.loopback = True
+        if self.cuda and self._comm is None:
+            self._comm = torch.cuda.Stream(device=self.net._flat.device)
 
     # -- bookkeeping ---------------------------------------------------------------------------------
     def reset(self):
@@ -217,7 +231,7 @@ class GradSync:
 
     def all_reduce(self, lo, hi):
         bucket = self.net._flat_grad[lo:hi]
-        if self.world == 1:
+        if self.world == 1 and not self.loopback:
             return
         if self._comm is None:
             self._exchange(bucket)
@@ -250,7 +264,7 @@ class TrainStep:
     """
 
     def __init__(self, net, opt, batch, attack=None, extract_from="y", use_graph=True, process_group=None,
-                 segmented=False, grad_exchange="fp32"):
+                 segmented=False, grad_exchange="fp32", loopback=False):
         self.net, self.opt, self.B = net, opt, int(batch)
         self.attack, self.extract_from = attack, extract_from
         dev = net._flat.device
@@ -268,6 +282,10 @@ class TrainStep:
         # RCCL all-reduces stay outside the captures and are issued between the replays (``segmented`` forces the same
         # structure on one rank, for tests)
         self.segmented = bool(segmented) or self.world > 1
+        if loopback:                                            # one-rank rehearsal: the chain of graphs with real collectives between them
+            self.sync.enable_loopback()
+            self.segmented = True
+        self.host_timing = None                                 # bench.py: seconds the host spent issuing one step's replays + collectives
         self._graph = None
         self._segments = None
         self.outputs = None
@@ -388,9 +406,12 @@ class TrainStep:
 
     def _replay_segments(self):
         graphs, launches = self._segments
+        t0 = time.perf_counter() if self.host_timing is not None else 0.0
         for i, (g, sends) in enumerate(zip(graphs, launches)):
             if i == len(graphs) - 1:
                 self.sync.finish()                              # the last graph (AdamW) waits for the collectives
             g.replay()
             for lo, hi in sends:
                 self.sync.all_reduce(lo, hi)
+        if self.host_timing is not None:
+            self.host_timing.append(time.perf_counter() - t0)

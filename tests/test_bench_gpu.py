@@ -57,6 +57,31 @@ def test_two_rank_rehearsal_of_config5_clips():
 
 
 @pytest.mark.gpu
+def test_one_rank_rccl_rehearsal_of_the_graph_chain():
+    """`--rehearse-rccl`: the N-rank call sequence on a ONE-rank RCCL group at config 5's per-GPU shape (2 clips x 10 tiles, the
+    26 ms step): every bucket's collective is really issued on the side stream between the graph replays (the gloo rehearsals
+    above never touch RCCL).  The sum over one rank is the identity, so the loss terms equal the plain single-graph run's; the
+    line reports how long the host needs to issue one step's replays and collectives."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--clip-seconds", "10", "--batch", "20", "--steps", "6", "--warmup", "2",
+            "--no-cpu-baseline", "--no-kernel-timing", "--no-secondary-legs", "--no-parity-mode-leg"]
+    lines = []
+    for extra in (["--rehearse-rccl"], []):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    reh, plain = lines
+    assert reh["n_gpus"] == 1 and reh["config"]["graph_segments"] >= 10 and plain["config"]["graph_segments"] == 1
+    ar = reh["allreduce"]
+    assert len(ar["buckets_in_launch_order"]) >= 10 and abs(sum(b["MB"] for b in ar["buckets_in_launch_order"]) - 274.9) < 1.0
+    assert all(b["ms"] > 0 for b in ar["buckets_in_launch_order"]) and "ONE rank" in ar["rehearsal"]
+    hi = ar["host_issue"]
+    assert hi["graphs"] == reh["config"]["graph_segments"] and hi["collectives"] == len(ar["buckets_in_launch_order"])
+    assert 0 < hi["ms_per_step_first"] < reh["ms_per_step"], hi          # the host stays ahead of the device at the 26 ms step
+    for p_, q_ in zip(reh["loss_terms"], plain["loss_terms"]):           # same steps, same streams: only the order of atomics differs
+        assert abs(p_ - q_) <= 1e-2 * max(abs(q_), 1e-2), (reh["loss_terms"], plain["loss_terms"])
+
+
+@pytest.mark.gpu
 def test_launcher_stops_when_a_rank_fails():
     """A rank that dies at start-up (here: --batch 7 with --clip-seconds 10 is rejected by every rank) ends the launcher with that
     rank's message on stderr instead of leaving the others in a collective until the distributed timeout."""

@@ -150,6 +150,50 @@ def test_gradsync_two_ranks_gloo(wm, tmp_path, xmode):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
 
 
+_LOOPBACK = r"""
+import importlib, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+wm = importlib.import_module("image-in-speech-watermarking_amd")
+net = wm.UformerAudio(modulator=True)
+sync = wm.GradSync(net)
+try:
+    sync.enable_loopback()
+    raise SystemExit("enable_loopback without a process group must raise")
+except RuntimeError:
+    pass
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
+dist.init_process_group("gloo", rank=0, world_size=1)
+sync = wm.GradSync(net, exchange=sys.argv[3])
+assert sync.world == 1 and not sync._active()
+sync.enable_loopback()
+calls = []
+orig = sync._exchange
+sync._exchange = lambda b: (calls.append(b.numel()), orig(b))
+net._flat_grad.copy_(torch.randn(net._flat_grad.numel(), generator=torch.Generator().manual_seed(5)))
+before = net._flat_grad.clone()
+for idx in range(3):
+    sync.segment_done(idx)
+sync.finish()
+n = net.optimized_numel
+assert sum(calls) == n and len(calls) == 3, calls               # the collectives were really issued, once per element
+want = before.bfloat16().float() if sys.argv[3] == "bf16" else before
+assert torch.equal(net._flat_grad[:n], want[:n]) and torch.equal(net._flat_grad[n:], before[n:])
+dist.destroy_process_group()
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("xmode", ["fp32", "bf16"])
+def test_gradsync_one_rank_loopback_issues_the_collectives(tmp_path, xmode):
+    """`GradSync.enable_loopback` (bench.py --rehearse-rccl): on a one-rank group every bucket's collective is issued; the sum
+    over one rank leaves the gradients as they are (bf16 exchange: rounded once)."""
+    script = tmp_path / "lb.py"
+    script.write_text(_LOOPBACK)
+    port = str(31500 + (os.getpid() + (11 if xmode == "bf16" else 0)) % 2000)
+    r = subprocess.run([sys.executable, str(script), ROOT, port, xmode], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_small_model_mirrors_keep_the_reference_state_dict_layout(wm):
     """Rows A18 / A19: ModelA and the HiDDeN decoder mirror the reference's parameter / buffer names and shapes."""
     from oracle import uformer_wm as O
