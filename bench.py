@@ -436,6 +436,20 @@ def main():
             allreduce["rehearsal"] = "ONE rank on RCCL (loopback): call sequence and host issue time only, the bus figures mean nothing"
     # the captured step holds 0.56 GB per tile; the legs below build their own steps at the same batch: give the memory back first
     step.release()
+    if a.rehearse_rccl:
+        # the same number of steps as ONE captured graph on a fresh copy of the model (same init, same Philox keys and step
+        # counter): the chain with the collectives between its graphs must leave the same loss terms (one-rank SUM = identity)
+        net1 = wm.UformerAudio(img_size=128, embed_dim=32, win_size=8, token_projection="linear", token_mlp="leff",
+                               depths=[1, 2, 8, 8, 2, 8, 8, 2, 1], modulator=True, dd_in=2, in_chans=2, audio_scale="0",
+                               compute_mode=a.mode)
+        load_synth(net1)
+        net1 = net1.to(dev).train()
+        opt1 = wm.FusedAdamW(net1, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+        step1 = wm.TrainStep(net1, opt1, a.batch, attack=attack, extract_from=extract_from, use_graph=not a.no_graph)
+        timed(step1, x, msg, a.steps, max(a.warmup, 2))
+        allreduce["single_graph_loss_terms"] = step1.losses.cpu().tolist()[:5]
+        step1.release()
+        del step1, opt1, net1
     ref_batch = identity = None
     if a.batch != 24 and not a.no_reference_batch and a.clip_seconds == 1:
         # the same step at the batch the reference script hard-codes (audio_uformer_stft.py:50), timed the same way

@@ -62,23 +62,19 @@ def test_one_rank_rccl_rehearsal_of_the_graph_chain():
     26 ms step): every bucket's collective is really issued on the side stream between the graph replays (the gloo rehearsals
     above never touch RCCL).  The sum over one rank is the identity, so the loss terms equal the plain single-graph run's; the
     line reports how long the host needs to issue one step's replays and collectives."""
-    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--clip-seconds", "10", "--batch", "20", "--steps", "6", "--warmup", "2",
-            "--no-cpu-baseline", "--no-kernel-timing", "--no-secondary-legs", "--no-parity-mode-leg"]
-    lines = []
-    for extra in (["--rehearse-rccl"], []):
-        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-2000:]
-        lines.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    reh, plain = lines
-    assert reh["n_gpus"] == 1 and reh["config"]["graph_segments"] >= 10 and plain["config"]["graph_segments"] == 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-rccl", "--clip-seconds", "10", "--batch", "20",
+                        "--steps", "6", "--warmup", "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    reh = json.loads(r.stdout.strip().splitlines()[-1])
+    assert reh["n_gpus"] == 1 and reh["config"]["graph_segments"] >= 10 and reh["config"]["baseline_config"] == 5
     ar = reh["allreduce"]
     assert len(ar["buckets_in_launch_order"]) >= 10 and abs(sum(b["MB"] for b in ar["buckets_in_launch_order"]) - 274.9) < 1.0
     assert all(b["ms"] > 0 for b in ar["buckets_in_launch_order"]) and "ONE rank" in ar["rehearsal"]
     hi = ar["host_issue"]
     assert hi["graphs"] == reh["config"]["graph_segments"] and hi["collectives"] == len(ar["buckets_in_launch_order"])
     assert 0 < hi["ms_per_step_first"] < reh["ms_per_step"], hi          # the host stays ahead of the device at the 26 ms step
-    for p_, q_ in zip(reh["loss_terms"], plain["loss_terms"]):           # same steps, same streams: only the order of atomics differs
-        assert abs(p_ - q_) <= 1e-2 * max(abs(q_), 1e-2), (reh["loss_terms"], plain["loss_terms"])
+    for p_, q_ in zip(reh["loss_terms"], ar["single_graph_loss_terms"]):  # same steps, same streams: only the order of atomics differs
+        assert abs(p_ - q_) <= 1e-2 * max(abs(q_), 1e-2), (reh["loss_terms"], ar["single_graph_loss_terms"])
 
 
 @pytest.mark.gpu
@@ -95,12 +91,13 @@ def test_launcher_stops_when_a_rank_fails():
 
 @pytest.mark.gpu
 def test_default_line_carries_config3_roofline_and_ber():
+    # (--ber-train-steps 200: the key and its plumbing; the trained state itself is tests/test_trained_ber_gpu.py's 2000 steps)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4",
-                        "--no-reference-batch", "--no-identity-leg"], capture_output=True, text=True, timeout=1500)
+                        "--no-reference-batch", "--no-identity-leg", "--ber-train-steps", "200"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["config"]["baseline_config"] == 3 and line["dtype"] == "bf16"
-    for k in ("roofline", "cpu_baseline", "ber", "mfma_path", "roofline_stft_path", "parity_mode", "config5", "fp32_mode"):
+    for k in ("roofline", "cpu_baseline", "ber", "ber_trained", "mfma_path", "roofline_stft_path", "parity_mode", "config5", "fp32_mode"):
         assert k in line, k
     assert line["config5"]["tiles_per_gpu"] == 20 and "10 s 16 kHz clips" in line["config5"]["workload"] and line["config5"]["value"] > 0
     assert line["fp32_mode"]["value"] > 0 and line["parity_mode"]["value"] > 0
