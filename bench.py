@@ -323,6 +323,12 @@ def main():
     a = parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(a))
+    # ONE JSON line on stdout and nothing else: libraries write to file descriptor 1 behind Python's back (RCCL prints its version
+    # block there when the first communicator is built — seen in the one-rank rehearsal on the box), and under torch.distributed.run
+    # rank 0's descriptor IS the job's stdout.  Everything this process writes to fd 1 goes to stderr; the line goes to the saved fd.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -551,8 +557,10 @@ def main():
         else:
             result["cpu_baseline_all_cores"] = {"skipped": f"{why}: the primary leg already runs on all {phys} usable cores"}
     if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(result) + "\n").encode())
+    os.close(line_fd)
+    if world > 1 or a.rehearse_rccl:
         dist.destroy_process_group()
 
 

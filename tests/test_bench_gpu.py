@@ -74,7 +74,8 @@ def test_one_rank_rccl_rehearsal_of_the_graph_chain():
     assert hi["graphs"] == reh["config"]["graph_segments"] and hi["collectives"] == len(ar["buckets_in_launch_order"])
     assert 0 < hi["ms_per_step_first"] < reh["ms_per_step"], hi          # the host stays ahead of the device at the 26 ms step
     for p_, q_ in zip(reh["loss_terms"], ar["single_graph_loss_terms"]):  # same steps, same streams: only the order of atomics differs
-        assert abs(p_ - q_) <= 1e-2 * max(abs(q_), 1e-2), (reh["loss_terms"], ar["single_graph_loss_terms"])
+        assert abs(p_ - q_) <= 1e-2 * abs(q_) + 5e-4, (reh["loss_terms"], ar["single_graph_loss_terms"])   # (measured: 9e-5 on the 1e-2 term)
+    assert r.stdout.strip().count("\n") == 0, r.stdout[:400]              # the line and nothing else (RCCL's version block goes to stderr)
 
 
 @pytest.mark.gpu
