@@ -208,14 +208,12 @@ __device__ __forceinline__ void cols_to_ring(float* ring, const u32x4 (&c)[NLD],
       const int ly = pix / NCOL, lx = pix - ly * NCOL;
       float f[H::NE];
       Chunk<ST>::unpack(c[k], f);
-      f32x2 xin[H::NE / 2], act[H::NE / 2];                       // the chunk's pairs advance through the polynomial in lock step
-#pragma unroll
-      for (int i = 0; i < H::NE; i += 2) xin[i / 2] = (f32x2){f[i], f[i + 1]};
-      GeluAct<ST, H::NE / 2>::run(xin, act);
 #pragma unroll
       for (int i = 0; i < H::NE; i += 2) {
-        f[i] = act[i / 2].x;
-        f[i + 1] = act[i / 2].y;
+        f32x2 a, g;
+        gelu_pair<ST>((f32x2){f[i], f[i + 1]}, a, g);
+        f[i] = a.x;
+        f[i + 1] = a.y;
       }
       float* dst = ring + ((ly * RING + ((gx0 + lx + 1) & (RING - 1))) * TC) + part * H::NE;
 #pragma unroll
@@ -270,15 +268,11 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(const ST* __restr
     for (int px = 0; px < TP; ++px) {
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) col[(px + 2) % 3][dy] = at(dy, px + 2);
-      // two accumulators taking the taps in turn: nine dependent packed FMAs cost a wait state each (see GeluAct)
-      f32x2 o = br, o2 = wr[1] * col[(px + 1) % 3][0];
+      f32x2 o = br;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        if (t == 1) continue;
-        const f32x2 v = wr[t] * col[(px + t % 3) % 3][t / 3];
-        if (t & 1) o2 += v; else o += v;
-      }
-      o += o2;
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) o += wr[dy * 3 + dx] * col[(px + dx) % 3][dy];
       const int64_t off = tile0 + px * Ch;                  // 32-bit multiply-add on top of the tile's 64-bit offset
       if (TRAIN) {
         f32x2 av, gv;

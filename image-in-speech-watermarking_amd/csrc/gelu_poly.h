@@ -56,38 +56,3 @@ template <> struct Gelu<__bf16> {
 template <typename ST>
 __device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& a, f32x2& g) { Gelu<ST>::pair(x, a, g); }
 
-// a[p] = x[p] Phi(x[p]) for NP pairs at once, no derivative.  One pair's Horner chain is eight DEPENDENT packed instructions, and
-// gfx950 wants a wait state between a packed fp32 result and its reader: evaluated pair after pair (as the unrolled loop over
-// gelu_pair came out of hipcc) every step of the chain was followed by an s_nop (93 of them in the forward strip kernel's staging
-// code).  Here the NP chains advance in lock step, so consecutive instructions are independent.  Same operations per element.
-template <typename ST, int NP> struct GeluAct {
-  static __device__ __forceinline__ void run(const f32x2 (&x)[NP], f32x2 (&a)[NP]) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      f32x2 g;
-      Gelu<ST>::pair(x[p], a[p], g);
-    }
-  }
-};
-template <int NP> struct GeluAct<__bf16, NP> {
-  static __device__ __forceinline__ void run(const f32x2 (&x)[NP], f32x2 (&a)[NP]) {
-    constexpr float c[7] = {1.043209509e-07f, -3.706793989e-06f, 7.615712969e-05f, -1.020840068e-03f, 9.580739327e-03f,
-                            -6.606320376e-02f, 3.988051945e-01f};
-    f32x2 z[NP], s[NP], q[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) z[p] = (f32x2){__builtin_amdgcn_fmed3f(x[p].x, -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x[p].y, -4.0f, 4.0f)};
-#pragma unroll
-    for (int p = 0; p < NP; ++p) s[p] = z[p] * z[p];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) q[p] = s[p] * -1.275896465e-09f + c[0];
-#pragma unroll
-    for (int k = 1; k < 7; ++k)
-#pragma unroll
-      for (int p = 0; p < NP; ++p) q[p] = q[p] * s[p] + c[k];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) q[p] = z[p] * q[p] + 0.5f;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) a[p] = x[p] * q[p];
-  }
-};
-
