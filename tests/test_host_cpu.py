@@ -394,3 +394,21 @@ def test_fused_adamw_is_an_optimizer_the_reference_schedulers_accept(wm):
         ref_on_fused = _lr_sequence(RefWarmup, tr.FusedAdamW(net, lr=2e-4))
         assert ref_on_fused == ref_on_stock
         assert mine == ref_on_stock
+
+
+def test_isa_report_reads_the_build(tmp_path):
+    """scripts/isa_report.py over the assembly `make` keeps under csrc/build: register totals, occupancy and instruction mix of the
+    step's kernels (skipped when the library was built elsewhere and only the .so travelled)."""
+    import glob
+    if not glob.glob(os.path.join(ROOT, "image-in-speech-watermarking_amd", "csrc", "build", "*-gfx950.s")):
+        pytest.skip("no assembly files next to the library")
+    out = tmp_path / "isa.md"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "isa_report.py"), "--md", str(out)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = {ln.split("`")[1]: [c.strip() for c in ln.split("|")] for ln in out.read_text().splitlines() if ln.startswith("| ") and "`" in ln}
+    pp = rows["gemm_nt_pp_kernel<0, 0>"]                          # 256 x 256 tile: 8 waves x 32 MFMAs per 32-deep stage, one workgroup per CU
+    assert pp[9] == "32" and pp[4] == "2" and pp[5] == "131072" and pp[6].startswith("1 ")
+    assert int(pp[3].split()[0]) <= 256 and pp[7] == "0 / 0"       # no spills in the dominant kernel
+    assert any(k.startswith("attn_half_bwd_kernel<128") for k in rows) and any(k.startswith("dwconv_fwd_strip_kernel<bf16, true>") for k in rows)
+
