@@ -3,8 +3,9 @@
 ``TrainStep`` = zero_grad -> forward -> attacks -> 4-term loss -> backward -> (gradient all-reduce) -> AdamW,
 issued as one stream of HIP kernel launches with nothing returning to the host; on one GPU the sequence is
 captured once into a hipGraph and replayed.  Data parallel: one process per GPU, the flat gradient arena is
-all-reduced over RCCL in three contiguous slices (extractor / decoder / encoder) on a side stream, each
-launched as soon as its part of backward has finished so the xGMI transfer overlaps the remaining backward.
+all-reduced over RCCL in ~25 MB buckets of finished arena runs (GradSync) on a side stream, each launched as
+soon as backward has produced it so the xGMI transfer overlaps the remaining backward; the captured step is
+then a chain of graphs cut at the bucket launches.
 """
 import time
 
