@@ -323,6 +323,8 @@ def main():
     a = parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(a))
+    if a.clip_seconds == 10 and a.batch % 10:                    # (every rank checks its own arguments, before it builds anything)
+        raise SystemExit("--clip-seconds 10 needs --batch to be a multiple of 10 tiles")
     # ONE JSON line on stdout and nothing else: libraries write to file descriptor 1 behind Python's back (RCCL prints its version
     # block there when the first communicator is built — seen in the one-rank rehearsal on the box), and under torch.distributed.run
     # rank 0's descriptor IS the job's stdout.  Everything this process writes to fd 1 goes to stderr; the line goes to the saved fd.
